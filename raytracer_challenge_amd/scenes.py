@@ -1,0 +1,206 @@
+"""Scene programs: the reference's `construct_world()` bodies restated as data, plus the synthetic
+benchmark scenes of BASELINE.json / SURVEY.md §8(d).
+
+Each function returns ``(Camera, World)`` built from :mod:`raytracer_challenge_amd.scene` values only —
+no native state — so the same scene can be handed to any backend.  Cameras default to the reference's
+native resolution; pass ``hsize``/``vsize`` to re-target (the BASELINE configs use 1920x1080 / 3840x2160).
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Tuple
+
+from .scene import (Camera, Color, Element, GroupKind, Material, Matrix, Noise, Pattern, PointLight, ShapeArgs, Vector, World)
+
+PI = math.pi
+ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
+
+
+def _cam(h, v, fov, frm, to, up, hsize=None, vsize=None) -> Camera:
+    return Camera.new(hsize or h, vsize or v, fov, Camera.transform(Vector.point(*frm), Vector.point(*to), Vector.vector(*up)))
+
+
+def default_world(hsize=11, vsize=11) -> Tuple[Camera, World]:
+    """World::default (src/world.rs:152-183) with the camera of src/image.rs:128-146."""
+    return _cam(11, 11, PI / 2.0, (0, 0, -5), (0, 0, 0), (0, 1, 0), hsize, vsize), World.default()
+
+
+def chapter11_glass_air_bubble(hsize=None, vsize=None) -> Tuple[Camera, World]:
+    """src/bin/chapter11_glass_air_bubble.rs:15-77 (BASELINE config 1 renders it at 200x100)."""
+    floor = Element.plane(ShapeArgs(
+        transform=Matrix.translation(0.0, -10.0, 0.0),
+        material=Material(pattern=Pattern.checkers(Matrix.id(), Pattern.plain(Color.white()), Pattern.plain(Color.black())), specular=0.0)))
+    glass = Element.sphere(ShapeArgs(material=Material(
+        pattern=Pattern.plain(Color.black()), diffuse=0.1, shininess=300.0, reflective=1.0, transparency=1.0, refractive_index=1.52)))
+    air = Element.sphere(ShapeArgs(transform=Matrix.scaling(0.5, 0.5, 0.5), material=Material(
+        pattern=Pattern.plain(Color.black()), diffuse=0.1, shininess=300.0, reflective=1.0, transparency=1.0, refractive_index=1.0)))
+    world = World([PointLight(Color.new(0.7, 0.7, 0.7), Vector.point(20.0, 10.0, 0.0))], [floor, glass, air])
+    return _cam(4096, 4096, PI / 3.0, (0.0, 2.5, 0.0), (0.0, 0.0, 0.0), (0.0, 0.0, 1.0), hsize, vsize), world
+
+
+def chapter11_title(hsize=None, vsize=None) -> Tuple[Camera, World]:
+    """src/bin/chapter11_title.rs:14-200 — six planes, seven spheres, stripes/checkers, two glass spheres."""
+    wall = Material(
+        pattern=Pattern.stripes(Matrix.scaling(0.25, 0.25, 0.25) * Matrix.rotation_y(PI / 2.0),
+                                Pattern.plain(Color.new(0.45, 0.45, 0.45)), Pattern.plain(Color.new(0.55, 0.55, 0.55))),
+        ambient=0.0, diffuse=0.4, specular=0.0, reflective=0.3)
+    floor = Element.plane(ShapeArgs(
+        transform=Matrix.rotation_y(0.31415),
+        material=Material(pattern=Pattern.checkers(Matrix.id(), Pattern.plain(Color.new(0.35, 0.35, 0.35)), Pattern.plain(Color.new(0.65, 0.65, 0.65))),
+                          specular=0.0, reflective=0.4)))
+    ceiling = Element.plane(ShapeArgs(transform=Matrix.translation(0.0, 5.0, 0.0),
+                                      material=Material(pattern=Pattern.plain(Color.new(0.8, 0.8, 0.8)), ambient=0.3, specular=0.0)))
+    west = Element.plane(ShapeArgs(transform=Matrix.translation(-5.0, 0.0, 0.0) * Matrix.rotation_z(PI / 2.0) * Matrix.rotation_y(PI / 2.0), material=wall))
+    east = Element.plane(ShapeArgs(transform=Matrix.translation(5.0, 0.0, 0.0) * Matrix.rotation_z(PI / 2.0) * Matrix.rotation_y(PI / 2.0), material=wall))
+    north = Element.plane(ShapeArgs(transform=Matrix.translation(0.0, 0.0, 5.0) * Matrix.rotation_x(PI / 2.0), material=wall))
+    south = Element.plane(ShapeArgs(transform=Matrix.translation(0.0, 0.0, -5.0) * Matrix.rotation_x(PI / 2.0), material=wall))
+
+    def ball(tx, ty, tz, s, rgb, **kw):
+        t = Matrix.translation(tx, ty, tz) if s is None else Matrix.translation(tx, ty, tz) * Matrix.scaling(s, s, s)
+        return Element.sphere(ShapeArgs(transform=t, material=Material(pattern=Pattern.plain(Color.new(*rgb)), **kw)))
+
+    glass = dict(ambient=0.0, diffuse=0.4, specular=0.9, shininess=300.0, reflective=0.9, transparency=0.9, refractive_index=1.5)
+    elements = [
+        floor, ceiling, west, east, north, south,
+        ball(4.6, 0.4, 1.0, 0.4, (0.8, 0.5, 0.3), shininess=50.0),
+        ball(4.7, 0.3, 0.4, 0.3, (0.9, 0.4, 0.5), shininess=50.0),
+        ball(-1.0, 0.5, 4.5, 0.5, (0.4, 0.9, 0.6), shininess=50.0),
+        ball(-1.7, 0.3, 4.7, 0.3, (0.4, 0.6, 0.9), shininess=50.0),
+        ball(-0.6, 1.0, 0.6, None, (1.0, 0.3, 0.2), specular=0.4, shininess=5.0),
+        ball(0.6, 0.7, -0.6, 0.7, (0.0, 0.0, 0.2), **glass),
+        ball(-0.7, 0.5, -0.8, 0.5, (0.0, 0.2, 0.0), **glass),
+    ]
+    world = World([PointLight(Color.white(), Vector.point(-4.9, 4.9, -1.0))], elements)
+    return _cam(4096, 2160, 1.152, (-2.6, 1.5, -3.9), (-0.6, 1.0, -0.8), (0.0, 1.0, 0.0), hsize, vsize), world
+
+
+def chapter14_hexagon(hsize=None, vsize=None) -> Tuple[Camera, World]:
+    """src/bin/chapter14_hexagon.rs:16-88 — nested groups of spheres + open cylinders, Simplex point-jitter."""
+    def corner():
+        return Element.sphere(ShapeArgs(transform=Matrix.translation(0.0, 0.0, -1.0) * Matrix.scaling(0.25, 0.25, 0.25)))
+
+    def edge():
+        return Element.cylinder(ShapeArgs(transform=Matrix.translation(0.0, 0.0, -1.0) * Matrix.rotation_y(-PI / 6.0)
+                                          * Matrix.rotation_z(-PI / 2.0) * Matrix.scaling(0.25, 1.0, 0.25)), 0.0, 1.0, False)
+
+    def side(t):
+        return Element.composite(t, None, GroupKind.Aggregation, [corner(), edge()])
+
+    material = Material(pattern=Pattern.point_jitter(
+        Noise.Simplex(0.3),
+        Pattern.stripes(Matrix.rotation_z(PI / 2.0) * Matrix.scaling(0.05, 0.05, 0.05), Pattern.plain(Color.white()), Pattern.plain(Color.black()))))
+    sides = [side(Matrix.rotation_y(float(n) * PI / 3.0)) for n in range(6)]
+    hexagon = Element.composite(Matrix.id(), material, GroupKind.Aggregation, sides)
+    world = World([PointLight(Color.white(), Vector.point(1.0, 6.9, -4.9))], [hexagon])
+    return _cam(4096, 2160, 0.314, (8.0, 5.0, 8.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), hsize, vsize), world
+
+
+def chapter14_benchmark(hsize=None, vsize=None) -> Tuple[Camera, World]:
+    """src/bin/chapter14_benchmark.rs:14-111 — plane + 8 nested groups x 125 spheres, gradient material."""
+    def sphere_block(n, h):
+        out = []
+        for x in range(n):
+            for z in range(n):
+                for y in range(n):
+                    out.append(Element.sphere(ShapeArgs(
+                        transform=Matrix.translation(0.1 + float(x) * h, 0.1 + float(y) * h, 0.1 + float(z) * h) * Matrix.scaling(0.1, 0.1, 0.1),
+                        material=Material(pattern=Pattern.plain(Color.black())))))
+        return out
+
+    backdrop = Element.plane(ShapeArgs(material=Material(pattern=Pattern.plain(Color.white()), specular=0.0)))
+    n, h = 5, 0.3
+    offset = float(n - 1) * (0.1 + h) - 0.1
+    groups = []
+    for x in range(2):
+        for z in range(2):
+            for y in range(2):
+                groups.append(Element.composite(Matrix.translation(float(x) * offset, float(y) * offset, float(z) * offset),
+                                                None, GroupKind.Aggregation, sphere_block(n, h)))
+    mat = Material(pattern=Pattern.gradient(Matrix.scaling(1.0, 2.9, 1.0) * Matrix.rotation_z(PI / 2.0),
+                                            Pattern.plain(Color.new(1.0, 0.0, 0.0)), Pattern.plain(Color.new(0.0, 0.0, 1.0))))
+    elements = [backdrop, Element.composite(Matrix.id(), mat, GroupKind.Aggregation, groups)]
+    world = World([PointLight(Color.white(), Vector.point(-5.0, 7.0, -1.0))], elements)
+    return _cam(4096, 2160, 1.0, (-8.0, 8.0, -8.0), (2.0, 2.0, 2.0), (0.0, 1.0, 0.0), hsize, vsize), world
+
+
+def chapter15_teapot(obj: str = "teapot_high.obj", hsize=None, vsize=None) -> Tuple[Camera, World]:
+    """src/bin/chapter15_teapot.rs:16-92.  BASELINE config 3 = teapot_low @1920x1080, config 4 = teapot_high @3840x2160."""
+    path = obj if os.path.isabs(obj) else os.path.join(ASSETS, "obj", obj)
+    teapot = Element.obj(path, Matrix.rotation_x(-PI / 2.0), Material(
+        pattern=Pattern.plain(Color.new(0.7, 0.7, 1.0)), ambient=0.1, diffuse=0.6, specular=0.4, reflective=0.1, shininess=5.0))
+    material = Material(pattern=Pattern.plain(Color.black()), ambient=0.02, diffuse=0.7, specular=0.0, reflective=0.5)
+    floor = Element.plane(ShapeArgs(material=material))
+    left = Element.plane(ShapeArgs(material=material, transform=Matrix.rotation_y(-PI / 4.0) * Matrix.translation(0.0, 0.0, 30.0) * Matrix.rotation_x(PI / 2.0)))
+    right = Element.plane(ShapeArgs(material=material, transform=Matrix.rotation_y(PI / 4.0) * Matrix.translation(0.0, 0.0, 30.0) * Matrix.rotation_x(PI / 2.0)))
+    world = World([PointLight(Color.new(0.7, 0.7, 0.7), Vector.point(-100.0, 100.0, -100.0)),
+                   PointLight(Color.new(0.7, 0.7, 0.7), Vector.point(100.0, 100.0, -100.0))],
+                  [floor, left, right, teapot])
+    return _cam(4096, 2160, 1.4, (0.0, 30.0, -50.0), (0.0, 0.0, 10.0), (0.0, 1.0, 0.0), hsize, vsize), world
+
+
+class SplitMix64:
+    """Documented generator for the synthetic scenes (seed 12345)."""
+
+    def __init__(self, seed: int):
+        self.s = seed & 0xFFFFFFFFFFFFFFFF
+
+    def next(self) -> int:
+        self.s = (self.s + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return z ^ (z >> 31)
+
+    def uniform(self, lo=0.0, hi=1.0) -> float:
+        return lo + (hi - lo) * ((self.next() >> 11) * (1.0 / 9007199254740992.0))
+
+
+def synthetic_analytic(n_primitives=512, seed=12345, cones=False, grouped=False, hsize=1920, vsize=1080) -> Tuple[Camera, World]:
+    """BASELINE config 2: 3 planes as in the teapot scene + ``n_primitives`` analytic primitives
+    placed uniformly in a 40x20x40 box above the floor; 60% matte / 25% reflective / 15% glass; 2 lights; fov 1.4.
+    cones=False: 50% spheres, 25% cubes, 25% closed cylinders (the headline variant);
+    cones=True: 40/25/25 + 10% closed cones.  grouped=True nests them into an 8-cell grid of Aggregation groups."""
+    rng = SplitMix64(seed)
+    plane_mat = Material(pattern=Pattern.plain(Color.black()), ambient=0.02, diffuse=0.7, specular=0.0, reflective=0.5)
+    floor = Element.plane(ShapeArgs(material=plane_mat))
+    left = Element.plane(ShapeArgs(material=plane_mat, transform=Matrix.rotation_y(-PI / 4.0) * Matrix.translation(0.0, 0.0, 30.0) * Matrix.rotation_x(PI / 2.0)))
+    right = Element.plane(ShapeArgs(material=plane_mat, transform=Matrix.rotation_y(PI / 4.0) * Matrix.translation(0.0, 0.0, 30.0) * Matrix.rotation_x(PI / 2.0)))
+    prims, cells = [], {}
+    for _ in range(n_primitives):
+        u = rng.uniform()
+        if cones:
+            kind = "sphere" if u < 0.40 else "cube" if u < 0.65 else "cylinder" if u < 0.90 else "cone"
+        else:
+            kind = "sphere" if u < 0.50 else "cube" if u < 0.75 else "cylinder"
+        px, py, pz = rng.uniform(-20.0, 20.0), rng.uniform(1.5, 21.5), rng.uniform(-15.0, 25.0)
+        s = rng.uniform(0.3, 1.5)
+        rx, ry, rz = rng.uniform(0.0, 2 * PI), rng.uniform(0.0, 2 * PI), rng.uniform(0.0, 2 * PI)
+        t = Matrix.translation(px, py, pz) * Matrix.rotation_z(rz) * Matrix.rotation_y(ry) * Matrix.rotation_x(rx) * Matrix.scaling(s, s, s)
+        col = Color.new(rng.uniform(0.1, 1.0), rng.uniform(0.1, 1.0), rng.uniform(0.1, 1.0))
+        m = rng.uniform()
+        if m < 0.60:
+            mat = Material(pattern=Pattern.plain(col), specular=0.3, shininess=50.0)
+        elif m < 0.85:
+            mat = Material(pattern=Pattern.plain(col), reflective=rng.uniform(0.2, 0.9))
+        else:
+            mat = Material(pattern=Pattern.plain(Color.new(col.r * 0.2, col.g * 0.2, col.b * 0.2)), diffuse=0.3, transparency=0.9, refractive_index=1.5, reflective=0.9)
+        args = ShapeArgs(transform=t, material=mat)
+        if kind == "sphere":
+            e = Element.sphere(args)
+        elif kind == "cube":
+            e = Element.cube(args)
+        elif kind == "cylinder":
+            e = Element.cylinder(args, 0.0, 1.0, True)
+        else:
+            e = Element.cone(args, -1.0, 0.0, True)
+        prims.append(e)
+        cells.setdefault((px >= 0.0, py >= 11.5, pz >= 5.0), []).append(e)
+    if grouped:
+        body = [Element.composite(Matrix.id(), None, GroupKind.Aggregation, v) for _, v in sorted(cells.items())]
+    else:
+        body = prims
+    world = World([PointLight(Color.new(0.7, 0.7, 0.7), Vector.point(-100.0, 100.0, -100.0)),
+                   PointLight(Color.new(0.7, 0.7, 0.7), Vector.point(100.0, 100.0, -100.0))],
+                  [floor, left, right] + body)
+    return _cam(1920, 1080, 1.4, (0.0, 30.0, -50.0), (0.0, 0.0, 10.0), (0.0, 1.0, 0.0), hsize, vsize), world
