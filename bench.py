@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path (BASELINE.json: "Mrays/sec at 1920x1080 depth-5; % HBM-roofline;
+1/2/4/8-GPU scaling").
+
+A *step* is one full frame: every rank traces its interleaved rows of the 1920x1080 image (fuel 5) with the HIP
+kernels and, for N > 1, the tiles are gathered to rank 0 over RCCL and de-interleaved.  Rays are *unique* rays
+(SURVEY.md §8d): primary + shadow + reflection + refraction casts, counted by the kernel's counting variant in an
+untimed pass (the count is deterministic).  Total work is fixed as N grows -> "strong" scaling.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2|config3|config2_cones] [--no-cpu-baseline]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes of the dominant (only) kernel per launch
+(SURVEY.md §8d formula on the kernel's own counters) / its average duration measured with HIP events on the stream it
+is launched on.  `cpu_baseline` = the CPU oracle (C++ restatement of the reference algorithm, NOT the Rust reference)
+timed on a bounded pixel sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def make_workload(name):
+    from raytracer_challenge_amd import scenes
+    if name == "config2":
+        cam, world = scenes.synthetic_analytic(n_primitives=512, seed=12345, cones=False, grouped=False, hsize=1920, vsize=1080)
+        desc = "BASELINE configs[1]: synthetic analytic scene (3 planes + 512 spheres/cubes/cylinders, seed 12345), 1920x1080, fuel 5"
+    elif name == "config2_cones":
+        cam, world = scenes.synthetic_analytic(n_primitives=512, seed=12345, cones=True, grouped=True, hsize=1920, vsize=1080)
+        desc = "configs[1] variant with 10% cones, grouped in 8 cells, 1920x1080, fuel 5"
+    elif name == "config3":
+        cam, world = scenes.chapter15_teapot("teapot_low.obj", 1920, 1080)
+        desc = "BASELINE configs[2]: chapter15 teapot scene, teapot_low.obj (240 smooth triangles) + BVH, 1920x1080, fuel 5"
+    elif name == "config3_high":
+        cam, world = scenes.chapter15_teapot("teapot_high.obj", 1920, 1080)
+        desc = "chapter15 teapot scene, teapot_high.obj (6320 smooth triangles) + BVH, 1920x1080, fuel 5"
+    else:
+        raise SystemExit("unknown workload %r" % name)
+    return cam, world, desc
+
+
+def cpu_baseline(world, cam, fuel, target_seconds=15.0):
+    """Oracle (CPU restatement) on a bounded, strided pixel sample of the same frame.  Returns the JSON object."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import oracle
+    orc = oracle()
+    nw = orc.build_world(world)
+    total = cam.hsize * cam.vsize
+    probe = np.arange(0, total, max(1, total // 2048), dtype=np.uint64)[:2048]
+    _, _, st = orc.render_timed(nw, cam, fuel, probe, threads=0)
+    per_px = max(st.seconds / len(probe), 1e-9)
+    n = int(min(total, max(4096, target_seconds / per_px)))
+    stride = max(1, total // n)
+    idx = np.arange(0, total, stride, dtype=np.uint64)
+    _, _, st = orc.render_timed(nw, cam, fuel, idx, threads=0)
+    return {
+        "value": st.unique_rays / st.seconds / 1e6, "unit": "Mrays/s", "cores": int(st.threads), "kind": "port",
+        "sample": "every %d-th pixel of the frame (%d px, %.1f s): oracle = C++ restatement of the reference algorithm "
+                  "(flat groups, all-hits + stable sort, per-light re-tracing), std::thread per logical core" % (stride, len(idx), st.seconds),
+        "reference_traced_mrays_per_s": st.traced_rays / st.seconds / 1e6,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="config2")
+    ap.add_argument("--fuel", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extra-workloads", default="config3", help="comma list measured (untimed region) and reported under 'extra' at N=1")
+    args = ap.parse_args()
+
+    import torch
+    import raytracer_challenge_amd as rt
+    from raytracer_challenge_amd.device import DeviceRenderer, algorithmic_bytes
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size != args.gpus:
+        if world_size == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world_size
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    hip = rt.hip_backend()  # raises if the HIP library is missing
+    cam, world, desc = make_workload(args.workload)
+    nw = hip.build_world(world)
+    dr = DeviceRenderer(hip, nw, cam, device=local_rank)
+    H, V = cam.hsize, cam.vsize
+    my_rows = len(range(rank, V, world_size))
+    max_rows = len(range(0, V, world_size))
+    tile = torch.zeros(max_rows * H * 3, dtype=torch.float64, device=dev)
+    gathered = [torch.zeros_like(tile) for _ in range(world_size)] if (world_size > 1 and rank == 0) else None
+    image = torch.zeros((V, H, 3), dtype=torch.float64, device=dev) if rank == 0 else None
+
+    def step(count=False):
+        st = dr.render_rows(args.fuel, rank, world_size, my_rows, tile, count=count, sync=True)
+        if world_size > 1:
+            dist.gather(tile, gathered, dst=0)
+            if rank == 0:
+                for r in range(world_size):
+                    nr = len(range(r, V, world_size))
+                    image[r::world_size] = gathered[r][: nr * H * 3].view(nr, H, 3)
+        return st
+
+    # untimed: counting variant -> unique rays + algorithmic bytes of this rank's launch
+    cst = step(count=True)
+    rays_local = torch.tensor([float(cst["unique_rays"])], dtype=torch.float64, device=dev)
+    if world_size > 1:
+        dist.all_reduce(rays_local)
+    rays_total = float(rays_local.item())
+
+    for _ in range(args.warmup):
+        step()
+    if world_size > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        kernel_ms.append(step()["kernel_ms"])
+    torch.cuda.synchronize()
+    if world_size > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world_size > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    if rank == 0:
+        avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+        alg_bytes = algorithmic_bytes(cst)
+        achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mrays/s (unique rays: primary+shadow+reflection+refraction) at 1920x1080 depth-5",
+            "value": rays_total * args.steps / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc, "hsize": H, "vsize": V, "fuel": args.fuel, "lights": nw.n_lights, "primitives": nw.primitive_count,
+                       "partition": "rows interleaved by rank, RCCL gather to rank 0" if world_size > 1 else "single GPU",
+                       "unique_rays_per_frame": rays_total, "rays_per_pixel": rays_total / (H * V)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "rtc_trace_kernel", "kernel_ms_avg": avg_kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "counters_rank0": {k: cst[k] for k in ("pixels", "unique_rays", "accel_nodes", "group_tests", "tri_tests", "analytic_tests", "rays_container")},
+                         "note": "scene (%d B) is L2/Infinity-Cache resident; real HBM traffic ~ framebuffer only (SURVEY.md §8d)" % dr.info()["scene_device_bytes"]},
+            "accelerator": dr.info(),
+        }
+        if world_size == 1:
+            extra = {}
+            for name in [w for w in args.extra_workloads.split(",") if w and w != args.workload]:
+                c2, w2, d2 = make_workload(name)
+                nw2 = hip.build_world(w2)
+                dr2 = DeviceRenderer(hip, nw2, c2, device=local_rank)
+                t2 = torch.zeros(c2.vsize * c2.hsize * 3, dtype=torch.float64, device=dev)
+                s2 = dr2.render_rows(args.fuel, 0, 1, c2.vsize, t2, count=True)
+                ms = [dr2.render_rows(args.fuel, 0, 1, c2.vsize, t2)["kernel_ms"] for _ in range(5)]
+                ms = sum(ms[1:]) / len(ms[1:])
+                extra[name] = {"workload": d2, "mrays_per_s_kernel": s2["unique_rays"] / ms / 1e3, "kernel_ms": ms, "unique_rays": s2["unique_rays"],
+                               "roofline_achieved_GBs": algorithmic_bytes(s2) / (ms * 1e-3) / 1e9, "accelerator": dr2.info()}
+            out["extra"] = extra
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(world, cam, args.fuel)
+        print(json.dumps(out), flush=True)
+    if world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

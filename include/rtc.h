@@ -1,0 +1,179 @@
+/* rtc.h — the drop-in boundary of the hot path: `Image::par_render(&Camera, &World) -> Image`
+ * (reference src/image.rs:65-81) and everything it calls (src/world.rs:18-149, src/intersection.rs:24-139,
+ * src/shape.rs:139-158/225-269/414-462/592-946, src/bounding_box.rs:80-92, src/material.rs:164-302,
+ * src/noise.rs:31-237, src/camera.rs:39-55), executed by hand-written HIP kernels on gfx950.
+ *
+ * The reference has no FFI of its own: the path sits behind one safe-Rust function.  A Rust
+ * maintainer replaces the body of `par_render` with: flatten `&World` into an `rtc_scene_desc` (plain arrays,
+ * field-wise copies — the Rust types are not #[repr(C)]), `rtc_scene_create`, `rtc_render`, copy the returned
+ * doubles into `Vec<Color>`.  INTEGRATION.md shows that shim.  Every record below names the reference item it
+ * carries.  All floating point is IEEE f64; matrices are row-major 4x4 exactly as `Matrix.data`.
+ *
+ * Ownership: `rtc_scene_create` copies everything it needs (the caller may free the arrays on return) and owns
+ * all device memory; the caller owns output buffers.  Errors: status code + `rtc_last_error()`; nothing unwinds.
+ * Threading: calls are blocking; distinct scenes may be used from distinct threads; one HIP stream per scene.
+ * There is no CPU fallback: without a HIP device every entry point that computes returns RTC_ERR_DEVICE.
+ */
+#ifndef RTC_H
+#define RTC_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rtc_scene rtc_scene;
+
+enum {
+  RTC_OK = 0,
+  RTC_ERR_INVALID = 1,     /* malformed description (index out of range, pattern too deep, ...)        */
+  RTC_ERR_UNSUPPORTED = 2, /* valid in the reference, not on device yet (CSG group kinds)             */
+  RTC_ERR_DEVICE = 3,      /* HIP failure / no device                                                   */
+  RTC_ERR_NAN = 4          /* a NaN intersection t was produced; the reference panics when it sorts it
+                              (src/intersection.rs:124)                                                 */
+};
+
+/* Geometry (src/shape.rs:466-498). */
+enum { RTC_SPHERE = 0, RTC_PLANE = 1, RTC_CUBE = 2, RTC_CYLINDER = 3, RTC_CONE = 4, RTC_TRIANGLE = 5, RTC_SMOOTH_TRIANGLE = 6 };
+enum { RTC_FLAG_CASTS_SHADOW = 1u, RTC_FLAG_CLOSED = 2u };
+
+/* Shape (src/shape.rs:297-306), one per primitive, in DFS order over world.elements (children in order).
+ * The index of a record is the primitive's sequence number: intersection ties resolve by it exactly as the
+ * reference's stable sort resolves them by insertion order (src/intersection.rs:123-125). */
+typedef struct rtc_prim {
+  int32_t geometry; /* RTC_SPHERE.. */
+  uint32_t flags;   /* RTC_FLAG_* : Shape.casts_shadow, Cylinder/Cone.closed */
+  int32_t material; /* index into materials (Shape.material) */
+  int32_t xform;    /* index into xforms (Shape.transform_inv / material_inv; shared by a whole OBJ group) */
+  int32_t data;     /* cylinder/cone: index into limits; triangles: index into tri_*; else -1 */
+} rtc_prim;
+
+/* Shape.transform_inv and Shape.material_inv after Element::propagate_inverses (src/shape.rs:47-72).
+ * Shape.transform_inv_tsp is not passed: it is bitwise transpose(transform_inv). */
+typedef struct rtc_xform {
+  double transform_inv[16];
+  double material_inv[16];
+} rtc_xform;
+
+/* Material (src/material.rs:19-28); `pattern` = index of the root rtc_pattern_node. */
+typedef struct rtc_material {
+  double ambient, diffuse, specular, shininess, reflective, transparency, refractive_index;
+  int32_t pattern;
+  int32_t _pad;
+} rtc_material;
+
+/* Pattern (src/material.rs:60-65) as a node array. */
+enum { RTC_PAT_DEBUG = 0, RTC_PAT_PLAIN = 1, RTC_PAT_JITTER = 2, RTC_PAT_MIXTURE = 3 };
+enum { RTC_JITTER_COLOR = 0, RTC_JITTER_POINT = 1 };
+enum { RTC_MIX_BLEND = 0, RTC_MIX_CHECKERS = 1, RTC_MIX_RING_GRADIENT = 2, RTC_MIX_RING = 3, RTC_MIX_GRADIENT = 4, RTC_MIX_STRIPES = 5 };
+enum { RTC_NOISE_SIMPLEX = 0, RTC_NOISE_FRACTAL = 1 };
+#define RTC_MAX_PATTERN_DEPTH 8
+typedef struct rtc_pattern_node {
+  int32_t tag;        /* RTC_PAT_* */
+  int32_t kind;       /* RTC_JITTER_* or RTC_MIX_* */
+  int32_t noise_kind; /* RTC_NOISE_* (jitter) */
+  uint32_t octaves;   /* Noise::Fractal.octaves */
+  int32_t left;       /* child node (jitter: the wrapped pattern), -1 if none */
+  int32_t right;
+  double scale;             /* Noise scale */
+  double color[3];          /* Plain */
+  double transform_inv[16]; /* Mixture.transform_inv */
+} rtc_pattern_node;
+
+/* PointLight (src/light.rs:5-8). */
+typedef struct rtc_light {
+  double intensity[3];
+  double origin[3];
+} rtc_light;
+
+/* The Element tree (src/shape.rs:31-34, :181-185) in DFS pre-order.  A group node carries the world-space
+ * bounding box the reference computed for it (Element::composite + propagate_inverses; NaN/inf included,
+ * SURVEY Q9) and `skip` = index of the first node after its subtree.  The device evaluates
+ * BoundingBox::intersects (src/bounding_box.rs:80-92) on exactly these numbers. */
+enum { RTC_NODE_PRIM = -1, RTC_NODE_UNION = 0, RTC_NODE_INTERSECTION = 1, RTC_NODE_DIFFERENCE = 2, RTC_NODE_AGGREGATION = 3 };
+typedef struct rtc_node {
+  int32_t kind; /* RTC_NODE_* */
+  int32_t ref;  /* RTC_NODE_PRIM: primitive index; groups: unused */
+  int32_t skip; /* groups: one past the subtree; primitives: own index + 1 */
+  int32_t _pad;
+  double bbox_min[3]; /* groups only */
+  double bbox_max[3];
+} rtc_node;
+
+typedef struct rtc_scene_desc {
+  uint32_t n_nodes;  const rtc_node* nodes;
+  uint32_t n_prims;  const rtc_prim* prims;
+  uint32_t n_xforms; const rtc_xform* xforms;
+  uint32_t n_limits; const double* limits;          /* n x {min, max}              (Geometry::Cylinder/Cone) */
+  uint32_t n_tris;   const double* tri_p1e1e2;      /* n x {p1, e1, e2} xyz        (src/shape.rs:369-412)    */
+                     const double* tri_normals;     /* n x {n1, n2, n3} xyz; flat triangles: {n, -, -}       */
+  uint32_t n_materials;     const rtc_material* materials;
+  uint32_t n_pattern_nodes; const rtc_pattern_node* pattern_nodes;
+  uint32_t n_lights;        const rtc_light* lights;
+} rtc_scene_desc;
+
+/* Camera (src/camera.rs:5-13) with its derived fields as Camera::new computes them (:16-37). */
+typedef struct rtc_camera {
+  uint64_t hsize, vsize;
+  double half_width, half_height, pixel_size;
+  double transform_inv[16];
+} rtc_camera;
+
+/* Parity channel: the nearest hit of a primary ray (t bit-exact; prim = sequence number or -1). */
+typedef struct rtc_hit {
+  double t;
+  int32_t prim;
+  int32_t push_idx;
+} rtc_hit;
+
+/* Work counters of one render call (deterministic for a given scene + accelerator). */
+typedef struct rtc_stats {
+  uint64_t pixels;
+  uint64_t rays_primary, rays_shadow, rays_reflect, rays_refract; /* unique rays, SURVEY.md §8d */
+  uint64_t rays_container;   /* extra n1/n2 passes (device-internal, not counted as rays)  */
+  uint64_t accel_nodes;      /* accelerator BVH nodes fetched (64 B each)                  */
+  uint64_t group_tests;      /* reference group boxes tested (BoundingBox::intersects)     */
+  uint64_t tri_tests;        /* triangles tested (72 B each)                               */
+  uint64_t analytic_tests;   /* analytic primitives tested (112 B each)                    */
+  uint64_t nan_ts;           /* NaN intersection t's seen (-> RTC_ERR_NAN)                 */
+  double kernel_ms;          /* device time of the trace kernel(s), HIP events on the scene's stream */
+  uint32_t n_launches;
+  uint32_t _pad;
+} rtc_stats;
+
+const char* rtc_last_error(void);
+/* Number of HIP devices visible (0 = none; never initialises a context). */
+int rtc_device_count(void);
+
+/* Flatten-once upload: validates, builds the results-neutral accelerator (BVH over each group's bounded
+ * primitive children) and copies SoA buffers to HBM on `device`. */
+int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out);
+void rtc_scene_destroy(rtc_scene*);
+/* Size in bytes of the scene's device buffers (accelerator included). */
+uint64_t rtc_scene_device_bytes(const rtc_scene*);
+
+/* Image::par_render for pixels i = first .. first+n-1 (row-major: x = i % hsize, y = i / hsize) or, when
+ * pixel_indices != NULL, for the n listed indices.  rgb: n*3 doubles (host).  hits, stats: optional. */
+int rtc_render(rtc_scene*, const rtc_camera*, int32_t fuel, const uint64_t* pixel_indices, uint64_t first, uint64_t n,
+               double* rgb, rtc_hit* hits, rtc_stats* stats);
+
+/* Same, output left in device memory (rgb_dev: n*3 doubles on the scene's device), for the rows
+ * row_first, row_first+row_step, ... (n_rows of them) — the tile-interleaved multi-GPU partition.
+ * Asynchronous on the scene's stream unless `sync` != 0.  count_stats != 0 uses the counting kernel variant. */
+int rtc_render_rows_device(rtc_scene*, const rtc_camera*, int32_t fuel, uint32_t row_first, uint32_t row_step, uint32_t n_rows,
+                           double* rgb_dev, rtc_stats* stats, int count_stats, int sync);
+
+/* World::color_at(ray, fuel) for n rays {ox,oy,oz,dx,dy,dz} (host arrays). */
+int rtc_trace_rays(rtc_scene*, const double* rays, uint64_t n, int32_t fuel, double* rgb, rtc_hit* hits, rtc_stats* stats);
+
+/* Blocks until the scene's stream is idle. */
+int rtc_scene_sync(rtc_scene*);
+
+/* Accelerator facts for reports: traversal-program length, BVH node count (64 B each), triangles packed into
+ * mesh BVH leaves, deepest BVH.  Any pointer may be NULL. */
+void rtc_scene_accel_info(const rtc_scene*, uint32_t* n_ops, uint32_t* n_bvh_nodes, uint32_t* n_mesh_tris, uint32_t* bvh_depth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

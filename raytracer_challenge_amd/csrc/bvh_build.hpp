@@ -1,0 +1,181 @@
+// bvh_build.hpp — host-side binned-SAH builder for the results-neutral accelerator.
+// Input: one f64 AABB per item.  Output: 64-byte DBvhNode records (children's boxes, f32 rounded outward after
+// a relative pad) appended to `nodes`, and the leaf-order permutation of the items.  No reference counterpart:
+// the reference tests every child of a group linearly (src/shape.rs:254-256).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <vector>
+
+#include "device_scene.h"
+
+namespace bvh {
+
+struct Item { double lo[3], hi[3]; };
+
+struct Builder {
+  const std::vector<Item>& items;
+  std::vector<DBvhNode>& nodes;
+  std::vector<uint32_t>& order;  // leaf-order item ids (local), appended; leaf refs index order positions + base
+  uint32_t base;                 // global offset of this BVH's first packed item
+  int max_depth = 0;
+  bool median_only = false;  // fallback when SAH produced a tree deeper than the traversal stack
+  static constexpr int kLeaf = 4, kBins = 16;
+
+  struct Range { double lo[3], hi[3]; };
+  static void grow(Range& r, const Item& it) {
+    for (int a = 0; a < 3; a++) { r.lo[a] = std::min(r.lo[a], it.lo[a]); r.hi[a] = std::max(r.hi[a], it.hi[a]); }
+  }
+  static Range none() {
+    const double inf = std::numeric_limits<double>::infinity();
+    return {{inf, inf, inf}, {-inf, -inf, -inf}};
+  }
+  static double area(const Range& r) {
+    double dx = r.hi[0] - r.lo[0], dy = r.hi[1] - r.lo[1], dz = r.hi[2] - r.lo[2];
+    if (!(dx >= 0 && dy >= 0 && dz >= 0)) return 0.0;
+    return 2.0 * (dx * dy + dy * dz + dz * dx);
+  }
+  static float down(double v) {
+    float f = (float)v;
+    if ((double)f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+    return f;
+  }
+  static float up(double v) {
+    float f = (float)v;
+    if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+    return f;
+  }
+  static void store(const Range& r, float* lo, float* hi) {
+    double ext = 0.0;
+    for (int a = 0; a < 3; a++) ext = std::max(ext, r.hi[a] - r.lo[a]);
+    for (int a = 0; a < 3; a++) {
+      double pl = 1e-9 * (std::fabs(r.lo[a]) + ext) + 1e-30, ph = 1e-9 * (std::fabs(r.hi[a]) + ext) + 1e-30;
+      lo[a] = down(r.lo[a] - pl);
+      hi[a] = up(r.hi[a] + ph);
+    }
+  }
+  static void store_absent(float* lo, float* hi) {
+    for (int a = 0; a < 3; a++) { lo[a] = std::numeric_limits<float>::infinity(); hi[a] = -std::numeric_limits<float>::infinity(); }
+  }
+
+  // Builds the subtree over ids[b,e); returns a child ref (>= 0 node, < 0 leaf) and its bounds.
+  int32_t build(std::vector<uint32_t>& ids, size_t b, size_t e, int depth, Range* bounds) {
+    max_depth = std::max(max_depth, depth);
+    Range box = none(), cbox = none();
+    for (size_t i = b; i < e; i++) {
+      grow(box, items[ids[i]]);
+      const Item& it = items[ids[i]];
+      for (int a = 0; a < 3; a++) {
+        double c = 0.5 * (it.lo[a] + it.hi[a]);
+        cbox.lo[a] = std::min(cbox.lo[a], c);
+        cbox.hi[a] = std::max(cbox.hi[a], c);
+      }
+    }
+    *bounds = box;
+    size_t n = e - b;
+    if (n <= (size_t)kLeaf) {
+      uint32_t first = base + (uint32_t)order.size();
+      for (size_t i = b; i < e; i++) order.push_back(ids[i]);
+      return ~(int32_t)((first << 3) | (uint32_t)(n - 1));
+    }
+    // binned SAH on the widest-centroid axes
+    int best_axis = -1, best_split = -1;
+    double best_cost = std::numeric_limits<double>::infinity();
+    for (int a = 0; a < 3 && !median_only; a++) {
+      double lo = cbox.lo[a], ext = cbox.hi[a] - cbox.lo[a];
+      if (!(ext > 0.0) || !std::isfinite(ext)) continue;
+      Range bb[kBins];
+      size_t cnt[kBins] = {0};
+      for (auto& r : bb) r = none();
+      double scale = kBins / ext;
+      for (size_t i = b; i < e; i++) {
+        const Item& it = items[ids[i]];
+        int k = (int)((0.5 * (it.lo[a] + it.hi[a]) - lo) * scale);
+        k = std::min(std::max(k, 0), kBins - 1);
+        cnt[k]++;
+        grow(bb[k], it);
+      }
+      double right_area[kBins];
+      size_t right_cnt[kBins];
+      Range acc = none();
+      size_t c = 0;
+      for (int k = kBins - 1; k > 0; k--) {
+        if (cnt[k]) { for (int q = 0; q < 3; q++) { acc.lo[q] = std::min(acc.lo[q], bb[k].lo[q]); acc.hi[q] = std::max(acc.hi[q], bb[k].hi[q]); } }
+        c += cnt[k];
+        right_area[k] = area(acc);
+        right_cnt[k] = c;
+      }
+      acc = none();
+      c = 0;
+      for (int k = 0; k < kBins - 1; k++) {
+        if (cnt[k]) { for (int q = 0; q < 3; q++) { acc.lo[q] = std::min(acc.lo[q], bb[k].lo[q]); acc.hi[q] = std::max(acc.hi[q], bb[k].hi[q]); } }
+        c += cnt[k];
+        if (c == 0 || right_cnt[k + 1] == 0) continue;
+        double cost = area(acc) * (double)c + right_area[k + 1] * (double)right_cnt[k + 1];
+        if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = k; }
+      }
+    }
+    size_t mid;
+    if (best_axis >= 0) {
+      double lo = cbox.lo[best_axis], scale = kBins / (cbox.hi[best_axis] - cbox.lo[best_axis]);
+      auto it = std::partition(ids.begin() + b, ids.begin() + e, [&](uint32_t id) {
+        int k = (int)((0.5 * (items[id].lo[best_axis] + items[id].hi[best_axis]) - lo) * scale);
+        k = std::min(std::max(k, 0), kBins - 1);
+        return k <= best_split;
+      });
+      mid = (size_t)(it - ids.begin());
+    } else if (median_only) {  // median of the widest centroid axis
+      int a = 0;
+      for (int q = 1; q < 3; q++)
+        if (cbox.hi[q] - cbox.lo[q] > cbox.hi[a] - cbox.lo[a]) a = q;
+      mid = b + n / 2;
+      std::nth_element(ids.begin() + b, ids.begin() + mid, ids.begin() + e, [&](uint32_t x, uint32_t y) {
+        return items[x].lo[a] + items[x].hi[a] < items[y].lo[a] + items[y].hi[a];
+      });
+    } else {
+      mid = b;
+    }
+    if (mid == b || mid == e) {  // all centroids coincide (or non-finite): split by count
+      mid = b + n / 2;
+    }
+    int32_t self = (int32_t)nodes.size();
+    nodes.emplace_back();
+    Range r0, r1;
+    int32_t c0 = build(ids, b, mid, depth + 1, &r0);
+    int32_t c1 = build(ids, mid, e, depth + 1, &r1);
+    DBvhNode& N = nodes[self];
+    store(r0, N.lo0, N.hi0);
+    store(r1, N.lo1, N.hi1);
+    N.c0 = c0;
+    N.c1 = c1;
+    N.pad[0] = N.pad[1] = 0;
+    return self;
+  }
+};
+
+// Returns the root node index (always an inner node, so traversal can start from a node).
+inline int32_t build(const std::vector<Item>& items, std::vector<DBvhNode>& nodes, std::vector<uint32_t>& order, uint32_t base, int* depth, bool median_only = false) {
+  Builder B{items, nodes, order, base};
+  B.median_only = median_only;
+  std::vector<uint32_t> ids(items.size());
+  for (uint32_t i = 0; i < ids.size(); i++) ids[i] = i;
+  Builder::Range r;
+  int32_t ref = B.build(ids, 0, ids.size(), 1, &r);
+  if (ref < 0) {  // a single leaf: wrap it so the root is a node
+    int32_t self = (int32_t)nodes.size();
+    nodes.emplace_back();
+    DBvhNode& N = nodes[self];
+    Builder::store(r, N.lo0, N.hi0);
+    Builder::store_absent(N.lo1, N.hi1);
+    N.c0 = ref;
+    N.c1 = ref;
+    N.pad[0] = N.pad[1] = 0;
+    ref = self;
+  }
+  if (depth) *depth = B.max_depth + 1;
+  return ref;
+}
+
+}  // namespace bvh

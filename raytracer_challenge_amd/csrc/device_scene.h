@@ -1,0 +1,98 @@
+// device_scene.h — layout of a flattened scene in HBM (shared by rtc_scene.cpp, which fills it, and
+// rtc_kernels.hip, which reads it).  Everything is SoA / fixed-size records, read-only during tracing.
+//
+// Traversal program ("ops"): the reference's Element tree (DFS pre-order) with every group's *bounded*
+// primitive children replaced by a results-neutral accelerator.  A ray walks the array once:
+//   OP_GROUP  a = group box index, b = pc to jump to when BoundingBox::intersects rejects the ray
+//   OP_PRIM   a = primitive index (exact test, own world->object matrix)
+//   OP_MESH   a = BVH root, b = xform index: triangles sharing one matrix; ray transformed once, BVH in
+//             object space, leaves index the packed triangle arrays (mtri / mtri_prim)
+//   OP_BVH    a = BVH root: world-space BVH over analytic primitives; leaves index item_prim
+//   OP_QUIRK  a = first, b = count in quirk_prim: the cubes and cones of the preceding OP_BVH, scanned linearly for
+//             rays in the state where the reference reports intersections outside the primitive's bounds
+// The accelerator may only skip primitives whose exact test would not produce an intersection with t inside
+// the interval the current pass cares about, so hit records are independent of it.
+#pragma once
+#include <stdint.h>
+
+enum { OP_PRIM = 0, OP_GROUP = 1, OP_MESH = 2, OP_BVH = 3, OP_QUIRK = 4 };
+
+struct DOp {
+  int32_t op, a, b, c;
+};
+
+// 64-byte BVH2 node: both children's boxes (f32, rounded outward) + child refs.
+// ref >= 0: inner node index.  ref < 0: leaf, items [first, first+count) with first = (~ref) >> 3,
+// count = ((~ref) & 7) + 1.  An absent child has an inverted box (lo = +inf, hi = -inf).
+struct DBvhNode {
+  float lo0[3], hi0[3];
+  float lo1[3], hi1[3];
+  int32_t c0, c1;
+  int32_t pad[2];
+};
+static_assert(sizeof(DBvhNode) == 64, "BVH node must be one 64-byte line");
+
+struct DPrim {  // 32 bytes
+  int32_t geom;
+  uint32_t flags;
+  int32_t mat;
+  int32_t xform;
+  int32_t data;
+  int32_t pad[3];
+};
+
+struct DPat {  // pattern node, 192 bytes
+  int32_t tag, kind, noise_kind;
+  uint32_t octaves;
+  int32_t left, right;
+  int32_t pad[2];
+  double scale;
+  double color[3];
+  double m[16];
+};
+
+struct DScene {
+  const DOp* ops;
+  const double* group_box;   // n_groups x {lo[3], hi[3]} f64 exactly as the reference computed them
+  const DBvhNode* bvh;
+  const double* mtri;        // packed leaf-order triangles x {p1, e1, e2}
+  const int32_t* mtri_prim;  // -> primitive sequence number
+  const int32_t* item_prim;  // OP_BVH leaf items -> primitive index
+  const int32_t* quirk_prim; // OP_QUIRK items -> primitive index (cubes, cones)
+  const DPrim* prims;
+  const double* xf_inv;      // n_xforms x 12 (rows 0..2 of Shape.transform_inv)
+  const double* xf_matinv;   // n_xforms x 16 (Shape.material_inv)
+  const double* limits;      // x {min, max}
+  const double* tri_geo;     // x {p1, e1, e2}
+  const double* tri_nrm;     // x {n1, n2, n3}
+  const double* mat;         // n_materials x 8 {ambient, diffuse, specular, shininess, reflective, transparency, refractive_index, -}
+  const int32_t* mat_pattern;
+  const DPat* pats;
+  const double* lights;      // n_lights x {intensity rgb, origin xyz}
+  int32_t n_ops, n_prims, n_lights;
+  int32_t all_cast_shadow;   // 1: every primitive casts a shadow -> shadow rays may stop at any hit
+};
+
+// Which pixels a launch covers.
+struct DPixelMap {
+  uint64_t n;                 // pixels in this launch
+  uint64_t first;             // mode 0: i = first + q
+  const uint64_t* indices;    // mode 1: i = indices[q]
+  uint32_t mode;              // 0 range, 1 list, 2 interleaved rows, 3 explicit rays
+  uint32_t row_first, row_step;  // mode 2: row = row_first + (q / hsize) * row_step, x = q % hsize
+  const double* rays;         // mode 3: n x {o, d}
+};
+
+struct DCamera {
+  uint64_t hsize, vsize;
+  double half_width, half_height, pixel_size;
+  double inv[16];
+};
+
+struct DStats {  // device-side counters (atomically accumulated per wave)
+  unsigned long long rays_primary, rays_shadow, rays_reflect, rays_refract, rays_container;
+  unsigned long long accel_nodes, group_tests, tri_tests, analytic_tests, nan_ts;
+};
+
+#define RTC_MAX_FUEL 16
+#define RTC_BVH_STACK 48

@@ -1,0 +1,843 @@
+// rtc_kernels.hip — hand-written HIP for gfx950 (MI355X): the reference's per-pixel path
+//   Image::par_render -> Camera::ray_at_pixel -> World::color_at -> {intersect, sort, hit, prepare_state,
+//   shade_hit -> {is_shadowed, Shape::lighting -> Pattern::color_at -> noise, reflected_color, refracted_color}}
+// (src/image.rs:65-81, src/camera.rs:39-55, src/world.rs:18-149, src/intersection.rs:24-139,
+//  src/shape.rs:414-462 + :592-946, src/bounding_box.rs:80-92, src/material.rs:164-302, src/noise.rs:31-237).
+//
+// All arithmetic is IEEE f64, compiled with -ffp-contract=off, in the reference's operation order wherever a
+// value can decide a hit.  What is *not* the reference's data flow:
+//   * no intersection lists, no sort: the nearest hit is the minimum of (t, primitive sequence, push index)
+//     over t >= 0 — exactly what "stable sort by t, first t >= 0" selects (src/intersection.rs:123-132);
+//   * n1/n2 (src/intersection.rs:70-103) come from one storage-free pass over the same ray: a shape is in the
+//     container list iff it has an odd number of intersections before the hit, and lists are ordered by each
+//     shape's last such intersection;
+//   * recursion (src/world.rs:84-132) is a per-lane stack of pending rays with scalar path weights; the
+//     reference's once-per-light re-tracing of identical subtrees (src/world.rs:58-79) becomes a factor L.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_scene.h"
+
+#define EPS 0.00001
+#define DINF (__builtin_inf())
+
+namespace {
+
+struct Ray { double ox, oy, oz, dx, dy, dz; };
+
+enum { MODE_CLOSEST = 0, MODE_SHADOW_ANY = 1, MODE_SHADOW_CLOSEST = 2, MODE_CONTAINERS = 3 };
+
+// Per-ray traversal state (registers).
+struct Trav {
+  int mode;
+  double tlo, thi;  // interval of t the pass cares about (accelerator culling only)
+  // nearest hit (CLOSEST / SHADOW_CLOSEST)
+  double best_t, best_u, best_v;
+  int best_prim, best_k, best_klast;
+  // SHADOW_ANY
+  double dist;
+  int shadowed;
+  // CONTAINERS: the hit key, and the two running "last container" candidates
+  double h_t;
+  int h_prim, h_klast;
+  double c1_t, c1_ri, c2_t, c2_ri;
+  int c1_prim, c2_prim;
+};
+
+struct Counters {
+  unsigned int accel_nodes, group_tests, tri_tests, analytic_tests, nan_ts;
+};
+
+// Rust f64::max/min: a NaN operand is ignored.
+__device__ __forceinline__ double rmax(double a, double b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
+__device__ __forceinline__ double rmin(double a, double b) { return (a != a) ? b : ((b != b) ? a : (a < b ? a : b)); }
+
+// src/shape.rs:635-653
+__device__ __forceinline__ void cube_axis(double origin, double direction, double mn, double mx, double& tmin, double& tmax) {
+  double a_num = mn - origin, b_num = mx - origin;
+  double a, b;
+  if (fabs(direction) >= EPS) {
+    a = a_num / direction;
+    b = b_num / direction;
+  } else {
+    a = a_num * DINF;
+    b = b_num * DINF;
+  }
+  if (a > b) { tmin = b; tmax = a; } else { tmin = a; tmax = b; }
+}
+
+// src/bounding_box.rs:80-92 on the group's f64 box
+__device__ __forceinline__ bool group_box_hit(const double* __restrict__ b, const Ray& r) {
+  double xa, xb, ya, yb, za, zb;
+  cube_axis(r.ox, r.dx, b[0], b[3], xa, xb);
+  cube_axis(r.oy, r.dy, b[1], b[4], ya, yb);
+  cube_axis(r.oz, r.dz, b[2], b[5], za, zb);
+  double t_min = rmax(rmax(xa, ya), za);
+  double t_max = rmin(rmin(xb, yb), zb);
+  return t_min <= t_max;
+}
+
+// Ray::transform (src/ray.rs:14-19) with Matrix*Vector (src/linalg/matrix.rs:261-284); origin.w = 1, direction.w = 0.
+__device__ __forceinline__ Ray to_object(const double* __restrict__ m, const Ray& r) {
+  Ray o;
+  o.ox = m[0] * r.ox + m[1] * r.oy + m[2] * r.oz + m[3] * 1.0;
+  o.oy = m[4] * r.ox + m[5] * r.oy + m[6] * r.oz + m[7] * 1.0;
+  o.oz = m[8] * r.ox + m[9] * r.oy + m[10] * r.oz + m[11] * 1.0;
+  o.dx = m[0] * r.dx + m[1] * r.dy + m[2] * r.dz + m[3] * 0.0;
+  o.dy = m[4] * r.dx + m[5] * r.dy + m[6] * r.dz + m[7] * 0.0;
+  o.dz = m[8] * r.dx + m[9] * r.dy + m[10] * r.dz + m[11] * 0.0;
+  return o;
+}
+
+// ---- feeding intersections of ONE primitive (in push order) to the current pass ------------------------
+__device__ __forceinline__ bool key_before(double t, int prim, int k, double ht, int hprim, int hk) {
+  return (t < ht) || (t == ht && (prim < hprim || (prim == hprim && k < hk)));
+}
+
+__device__ __forceinline__ void accept(const DScene& S, Trav& T, Counters& C, int prim, int n, const double* t, double u, double v) {
+  if (n == 0) return;
+  if (T.mode == MODE_CLOSEST || T.mode == MODE_SHADOW_CLOSEST) {
+    for (int k = 0; k < n; k++) {
+      double tk = t[k];
+      if (tk != tk) C.nan_ts++;
+      if (tk >= 0.0) {
+        if (tk < T.best_t || (tk == T.best_t && prim < T.best_prim)) {
+          T.best_t = tk; T.best_prim = prim; T.best_k = k; T.best_klast = k; T.best_u = u; T.best_v = v;
+          T.thi = tk;
+        } else if (tk == T.best_t && prim == T.best_prim) {
+          T.best_klast = k;
+        }
+      }
+    }
+  } else if (T.mode == MODE_SHADOW_ANY) {
+    for (int k = 0; k < n; k++) {
+      double tk = t[k];
+      if (tk != tk) C.nan_ts++;
+      if (tk >= 0.0 && tk < T.dist) T.shadowed = 1;
+    }
+  } else {  // MODE_CONTAINERS
+    int cnt1 = 0, cnt2 = 0;
+    double m1 = 0.0, m2 = 0.0;
+    for (int k = 0; k < n; k++) {
+      double tk = t[k];
+      bool b1 = key_before(tk, prim, k, T.h_t, T.h_prim, T.h_klast);
+      bool b2 = b1 || (tk == T.h_t && prim == T.h_prim && k == T.h_klast);
+      // pushes of one primitive are visited in push order, so "largest key so far" = latest k among the largest t
+      if (b1) { if (cnt1 == 0 || tk >= m1) m1 = tk; cnt1++; }
+      if (b2) { if (cnt2 == 0 || tk >= m2) m2 = tk; cnt2++; }
+    }
+    if ((cnt1 & 1) && (T.c1_prim < 0 || m1 > T.c1_t || (m1 == T.c1_t && prim > T.c1_prim))) {
+      T.c1_t = m1; T.c1_prim = prim; T.c1_ri = S.mat[8 * S.prims[prim].mat + 6];
+    }
+    if ((cnt2 & 1) && (T.c2_prim < 0 || m2 > T.c2_t || (m2 == T.c2_t && prim > T.c2_prim))) {
+      T.c2_t = m2; T.c2_prim = prim; T.c2_ri = S.mat[8 * S.prims[prim].mat + 6];
+    }
+  }
+}
+
+// Geometry::intersect_triangle (src/shape.rs:824-860); o = object-space ray
+__device__ __forceinline__ int tri_hit(const double* __restrict__ g, const Ray& o, double& t, double& u, double& v) {
+  double p1x = g[0], p1y = g[1], p1z = g[2], e1x = g[3], e1y = g[4], e1z = g[5], e2x = g[6], e2y = g[7], e2z = g[8];
+  double cx = o.dy * e2z - o.dz * e2y, cy = o.dz * e2x - o.dx * e2z, cz = o.dx * e2y - o.dy * e2x;  // dir x e2
+  double det = e1x * cx + e1y * cy + e1z * cz;
+  if (fabs(det) < EPS) return 0;
+  double f = 1.0 / det;
+  double sx = o.ox - p1x, sy = o.oy - p1y, sz = o.oz - p1z;  // p1_to_origin
+  u = f * (sx * cx + sy * cy + sz * cz);
+  if (u < 0.0 || u > 1.0) return 0;
+  double qx = sy * e1z - sz * e1y, qy = sz * e1x - sx * e1z, qz = sx * e1y - sy * e1x;  // origin x e1
+  v = f * (o.dx * qx + o.dy * qy + o.dz * qz);
+  if (v < 0.0 || u + v > 1.0) return 0;
+  t = f * (e2x * qx + e2y * qy + e2z * qz);
+  return 1;
+}
+
+// Geometry::intersect (src/shape.rs:862-885) for one primitive; returns the number of pushes, in push order.
+__device__ __forceinline__ int prim_hits(const DScene& S, const DPrim& P, const Ray& o, double* t, double& u, double& v) {
+  int n = 0;
+  switch (P.geom) {
+    case 0: {  // sphere :592-619
+      double a = o.dx * o.dx + o.dy * o.dy + o.dz * o.dz;
+      double b = 2.0 * (o.dx * o.ox + o.dy * o.oy + o.dz * o.oz);
+      double c = (o.ox * o.ox + o.oy * o.oy + o.oz * o.oz) - 1.0;
+      double disc = b * b - 4.0 * a * c;
+      if (disc < 0.0) return 0;
+      double sq = sqrt(disc);
+      t[0] = (-b - sq) / (2.0 * a);
+      t[1] = (-b + sq) / (2.0 * a);
+      return 2;
+    }
+    case 1: {  // plane :621-633
+      if (fabs(o.dy - 0.0) < EPS) return 0;
+      t[0] = -o.oy / o.dy;
+      return 1;
+    }
+    case 2: {  // cube :655-679
+      double xa, xb, ya, yb, za, zb;
+      cube_axis(o.ox, o.dx, -1.0, 1.0, xa, xb);
+      cube_axis(o.oy, o.dy, -1.0, 1.0, ya, yb);
+      cube_axis(o.oz, o.dz, -1.0, 1.0, za, zb);
+      double t_min = rmax(rmax(xa, ya), za);
+      double t_max = rmin(rmin(xb, yb), zb);
+      if (t_min <= t_max) { t[0] = t_min; t[1] = t_max; return 2; }
+      return 0;
+    }
+    case 3:
+    case 4: {  // cylinder :724-768, cone :770-822
+      double mn = S.limits[2 * P.data], mx = S.limits[2 * P.data + 1];
+      bool cone = P.geom == 4;
+      double a, b, c;
+      bool walls;
+      if (!cone) {
+        a = o.dx * o.dx + o.dz * o.dz;
+        walls = !(fabs(a - 0.0) < EPS);
+        b = 2.0 * o.ox * o.dx + 2.0 * o.oz * o.dz;
+        c = o.ox * o.ox + o.oz * o.oz - 1.0;
+      } else {
+        a = o.dx * o.dx - o.dy * o.dy + o.dz * o.dz;
+        b = 2.0 * o.ox * o.dx - 2.0 * o.oy * o.dy + 2.0 * o.oz * o.dz;
+        c = o.ox * o.ox - o.oy * o.oy + o.oz * o.oz;
+        bool a0 = fabs(a - 0.0) < EPS, b0 = fabs(b - 0.0) < EPS;
+        walls = !a0;
+        if (a0 && !b0) t[n++] = -c / (2.0 * b);  // single-root branch :812-818
+      }
+      if (walls) {
+        double disc = b * b - 4.0 * a * c;
+        if (disc >= 0.0) {
+          double sq = sqrt(disc);
+          double t0 = (-b - sq) / (2.0 * a);
+          double y0 = o.oy + t0 * o.dy;
+          if (mn < y0 && y0 < mx) t[n++] = t0;
+          double t1 = (-b + sq) / (2.0 * a);
+          double y1 = o.oy + t1 * o.dy;
+          if (mn < y1 && y1 < mx) t[n++] = t1;
+        }
+      }
+      // intersect_cap :681-722 (cylinder radii 1,1; cone radii min,max)
+      if ((P.flags & 2u) && !(fabs(o.dy - 0.0) < EPS)) {
+        double r0 = cone ? mn : 1.0, r1 = cone ? mx : 1.0;
+        double tc = (mn - o.oy) / o.dy;
+        double x = o.ox + tc * o.dx, z = o.oz + tc * o.dz;
+        if ((x * x + z * z) <= r0 * r0) t[n++] = tc;
+        tc = (mx - o.oy) / o.dy;
+        x = o.ox + tc * o.dx; z = o.oz + tc * o.dz;
+        if ((x * x + z * z) <= r1 * r1) t[n++] = tc;
+      }
+      return n;
+    }
+    default:  // triangles :824-860
+      return tri_hit(S.tri_geo + 9 * P.data, o, t[0], u, v);
+  }
+}
+
+// Shape::intersect (src/shape.rs:414-417) for one primitive.
+// Two reference quirks let a primitive report an intersection OUTSIDE any finite bound of its surface, so a
+// bounding-volume hierarchy alone would lose them:
+//   cube: an axis with |direction| < EPSILON only requires the ORIGIN to be inside the slab (src/shape.rs:641-648);
+//   cone: when a ~ 0 the single root -c/(2b) is pushed without the min < y < max check (src/shape.rs:812-818).
+// Rays in that state ("quirk rays" for this primitive) are tested by the linear OP_QUIRK pass and skipped in
+// the BVH leaf; all other rays are tested in the leaf only.  policy: 0 always, 1 skip if quirk, 2 only if quirk.
+__device__ __forceinline__ void visit_prim(const DScene& S, int prim, const Ray& r, Trav& T, Counters& C, int policy) {
+  DPrim P = S.prims[prim];
+  Ray o = to_object(S.xf_inv + 12 * P.xform, r);
+  if (policy != 0) {
+    bool quirk = false;
+    if (P.geom == 2) quirk = fabs(o.dx) < EPS || fabs(o.dy) < EPS || fabs(o.dz) < EPS;
+    else if (P.geom == 4) quirk = fabs((o.dx * o.dx - o.dy * o.dy + o.dz * o.dz) - 0.0) < EPS;
+    if (quirk != (policy == 2)) return;
+  }
+  double t[4], u = 0.0, v = 0.0;
+  if (P.geom >= 5) C.tri_tests++; else C.analytic_tests++;
+  int n = prim_hits(S, P, o, t, u, v);
+  accept(S, T, C, prim, n, t, u, v);
+}
+
+// ---- accelerator -------------------------------------------------------------------------------------
+// Slab test against an f32 box widened at build time; evaluated in f64, NaN-ignoring min/max, so a box is
+// only rejected when the ray's line misses it or its [tn, tf] misses [tlo, thi].  Returns entry distance.
+__device__ __forceinline__ bool slab(const float* __restrict__ lo, const float* __restrict__ hi, const Ray& o, double ix, double iy, double iz,
+                                     double tlo, double thi, double& tn_out) {
+  double t0 = ((double)lo[0] - o.ox) * ix, t1 = ((double)hi[0] - o.ox) * ix;
+  double tn = fmin(t0, t1), tf = fmax(t0, t1);
+  t0 = ((double)lo[1] - o.oy) * iy; t1 = ((double)hi[1] - o.oy) * iy;
+  tn = fmax(tn, fmin(t0, t1)); tf = fmin(tf, fmax(t0, t1));
+  t0 = ((double)lo[2] - o.oz) * iz; t1 = ((double)hi[2] - o.oz) * iz;
+  tn = fmax(tn, fmin(t0, t1)); tf = fmin(tf, fmax(t0, t1));
+  tn_out = tn;
+  return fmax(tn, tlo) <= fmin(tf, thi) && lo[0] <= hi[0];
+}
+
+template <bool MESH>
+__device__ __forceinline__ void bvh_walk(const DScene& S, int root, const Ray& world, const Ray& o, Trav& T, Counters& C, int* __restrict__ stack, int stride) {
+  // t-interval slack: the exact tests and the slab test round differently
+  const double ix = 1.0 / o.dx, iy = 1.0 / o.dy, iz = 1.0 / o.dz;
+  int sp = 0;
+  int cur = root;
+  for (;;) {
+    if (cur >= 0) {
+      const DBvhNode* N = S.bvh + cur;
+      C.accel_nodes++;
+      double slack = 1e-7 * fmax(fabs(T.thi), 1.0);
+      double lo = T.tlo - ((T.tlo == -DINF) ? 0.0 : 1e-7 * fmax(fabs(T.tlo), 1.0)), hi = (T.thi == DINF) ? DINF : T.thi + slack;
+      double n0, n1;
+      bool h0 = slab(N->lo0, N->hi0, o, ix, iy, iz, lo, hi, n0);
+      bool h1 = slab(N->lo1, N->hi1, o, ix, iy, iz, lo, hi, n1);
+      int c0 = N->c0, c1 = N->c1;
+      if (h0 && h1) {
+        if (n1 < n0) { int tmp = c0; c0 = c1; c1 = tmp; }
+        stack[sp * stride] = c1;
+        sp++;
+        cur = c0;
+        continue;
+      } else if (h0) { cur = c0; continue; }
+      else if (h1) { cur = c1; continue; }
+    } else {
+      int first = (~cur) >> 3, cnt = ((~cur) & 7) + 1;
+      for (int i = first; i < first + cnt; i++) {
+        if (MESH) {
+          double t, u, v;
+          C.tri_tests++;
+          if (tri_hit(S.mtri + 9 * (size_t)i, o, t, u, v)) accept(S, T, C, S.mtri_prim[i], 1, &t, u, v);
+        } else {
+          visit_prim(S, S.item_prim[i], world, T, C, 1);
+        }
+      }
+      if (T.mode == MODE_SHADOW_ANY && T.shadowed) return;
+    }
+    if (sp == 0) return;
+    sp--;
+    cur = stack[sp * stride];
+  }
+}
+
+// World::intersect (src/world.rs:18-24) + Group::intersect (src/shape.rs:248-269) over the flattened program.
+__device__ __forceinline__ void traverse(const DScene& S, const Ray& r, Trav& T, Counters& C, int* __restrict__ stack, int stride) {
+  int pc = 0;
+  const int n = S.n_ops;
+  while (pc < n) {
+    DOp op = S.ops[pc];
+    if (op.op == OP_PRIM) {
+      visit_prim(S, op.a, r, T, C, 0);
+      pc++;
+    } else if (op.op == OP_QUIRK) {
+      for (int i = op.a; i < op.a + op.b; i++) visit_prim(S, S.quirk_prim[i], r, T, C, 2);
+      pc++;
+    } else if (op.op == OP_GROUP) {
+      C.group_tests++;
+      pc = group_box_hit(S.group_box + 6 * op.a, r) ? pc + 1 : op.b;
+    } else if (op.op == OP_MESH) {
+      Ray o = to_object(S.xf_inv + 12 * op.b, r);
+      bvh_walk<true>(S, op.a, r, o, T, C, stack, stride);
+      pc++;
+    } else {
+      bvh_walk<false>(S, op.a, r, r, T, C, stack, stride);
+      pc++;
+    }
+    if (T.mode == MODE_SHADOW_ANY && T.shadowed) return;
+  }
+}
+
+// ---- noise (src/noise.rs) ------------------------------------------------------------------------------
+__device__ const unsigned char PERM[256] = {
+    151, 160, 137, 91,  90,  15,  131, 13,  201, 95,  96,  53,  194, 233, 7,   225, 140, 36,  103, 30,  69,  142, 8,   99,  37,  240,
+    21,  10,  23,  190, 6,   148, 247, 120, 234, 75,  0,   26,  197, 62,  94,  252, 219, 203, 117, 35,  11,  32,  57,  177, 33,  88,
+    237, 149, 56,  87,  174, 20,  125, 136, 171, 168, 68,  175, 74,  165, 71,  134, 139, 48,  27,  166, 77,  146, 158, 231, 83,  111,
+    229, 122, 60,  211, 133, 230, 220, 105, 92,  41,  55,  46,  245, 40,  244, 102, 143, 54,  65,  25,  63,  161, 1,   216, 80,  73,
+    209, 76,  132, 187, 208, 89,  18,  169, 200, 196, 135, 130, 116, 188, 159, 86,  164, 100, 109, 198, 173, 186, 3,   64,  52,  217,
+    226, 250, 124, 123, 5,   202, 38,  147, 118, 126, 255, 82,  85,  212, 207, 206, 59,  227, 47,  16,  58,  17,  182, 189, 28,  42,
+    223, 183, 170, 213, 119, 248, 152, 2,   44,  154, 163, 70,  221, 153, 101, 155, 167, 43,  172, 9,   129, 22,  39,  253, 19,  98,
+    108, 110, 79,  113, 224, 232, 178, 185, 112, 104, 218, 246, 97,  228, 251, 34,  242, 193, 238, 210, 144, 12,  191, 179, 162, 241,
+    81,  51,  145, 235, 249, 14,  239, 107, 49,  192, 214, 31,  181, 199, 106, 157, 184, 84,  204, 176, 115, 121, 50,  45,  127, 4,
+    150, 254, 138, 236, 205, 93,  222, 114, 67,  29,  24,  72,  243, 141, 128, 195, 78,  66,  215, 61,  156, 180};
+
+__device__ __forceinline__ unsigned nhash(unsigned i) { return PERM[i & 255u]; }  // :90-92, table period 256
+
+__device__ __forceinline__ int as_i32(double x) {  // Rust `as i32`: saturating, NaN -> 0
+  if (x != x) return 0;
+  if (x >= 2147483647.0) return 2147483647;
+  if (x <= -2147483648.0) return (int)0x80000000;
+  return (int)x;
+}
+__device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+__device__ __forceinline__ int fast_floor(double x) { return x > 0.0 ? as_i32(x) : (int)((unsigned)as_i32(x) - 1u); }  // :116-122
+__device__ __forceinline__ unsigned modulus256(int x) { int a = x % 256; return a < 0 ? (unsigned)(a + 256) : (unsigned)a; }  // :124-131
+
+__device__ __forceinline__ double ngrad(unsigned h, double x, double y, double z) {  // :94-114
+  switch (h & 0xF) {
+    case 0x0: return x + y;
+    case 0x1: return -x + y;
+    case 0x2: return x - y;
+    case 0x3: return -x - y;
+    case 0x4: return x + z;
+    case 0x5: return -x + z;
+    case 0x6: return x - z;
+    case 0x7: return -x - z;
+    case 0x8: return y + z;
+    case 0x9: return -y + z;
+    case 0xA: return y - z;
+    case 0xB: return -y - z;
+    case 0xC: return y + x;
+    case 0xD: return -y + z;
+    case 0xE: return y - x;
+    default: return -y - z;
+  }
+}
+
+__device__ __noinline__ double simplex3(double x, double y, double z) {  // :134-219
+  const double F3 = 1.0 / 3.0, G3 = 1.0 / 6.0;
+  double s = (x + y + z) * F3;
+  int i = fast_floor(x + s), j = fast_floor(y + s), k = fast_floor(z + s);
+  double t = (double)wadd(wadd(i, j), k) * G3;
+  double x0 = x - ((double)i - t), y0 = y - ((double)j - t), z0 = z - ((double)k - t);
+  int i1, j1, k1, i2, j2, k2;
+  if (x0 >= y0) {
+    if (y0 >= z0) { i1 = 1; j1 = 0; k1 = 0; i2 = 1; j2 = 1; k2 = 0; }
+    else if (x0 >= z0) { i1 = 1; j1 = 0; k1 = 0; i2 = 1; j2 = 0; k2 = 1; }
+    else { i1 = 0; j1 = 0; k1 = 1; i2 = 1; j2 = 0; k2 = 1; }
+  } else {
+    if (y0 < z0) { i1 = 0; j1 = 0; k1 = 1; i2 = 0; j2 = 1; k2 = 1; }
+    else if (x0 < z0) { i1 = 0; j1 = 1; k1 = 0; i2 = 0; j2 = 1; k2 = 1; }
+    else { i1 = 0; j1 = 1; k1 = 0; i2 = 1; j2 = 1; k2 = 0; }
+  }
+  double x1 = x0 - (double)i1 + G3, y1 = y0 - (double)j1 + G3, z1 = z0 - (double)k1 + G3;
+  double x2 = x0 - (double)i2 + 2.0 * G3, y2 = y0 - (double)j2 + 2.0 * G3, z2 = z0 - (double)k2 + 2.0 * G3;
+  double x3 = x0 - 1.0 + 3.0 * G3, y3 = y0 - 1.0 + 3.0 * G3, z3 = z0 - 1.0 + 3.0 * G3;
+  unsigned ii = modulus256(i), jj = modulus256(j), kk = modulus256(k);
+  unsigned gi0 = nhash(ii + nhash(jj + nhash(kk)));
+  unsigned gi1 = nhash(ii + i1 + nhash(jj + j1 + nhash(kk + k1)));
+  unsigned gi2 = nhash(ii + i2 + nhash(jj + j2 + nhash(kk + k2)));
+  unsigned gi3 = nhash(ii + 1 + nhash(jj + 1 + nhash(kk + 1)));
+  double n0, n1, n2, n3;
+  double t0 = 0.6 - x0 * x0 - y0 * y0 - z0 * z0;
+  if (t0 < 0.0) n0 = 0.0; else { t0 *= t0; n0 = t0 * t0 * ngrad(gi0, x0, y0, z0); }
+  double t1 = 0.6 - x1 * x1 - y1 * y1 - z1 * z1;
+  if (t1 < 0.0) n1 = 0.0; else { t1 *= t1; n1 = t1 * t1 * ngrad(gi1, x1, y1, z1); }
+  double t2 = 0.6 - x2 * x2 - y2 * y2 - z2 * z2;
+  if (t2 < 0.0) n2 = 0.0; else { t2 *= t2; n2 = t2 * t2 * ngrad(gi2, x2, y2, z2); }
+  double t3 = 0.6 - x3 * x3 - y3 * y3 - z3 * z3;
+  if (t3 < 0.0) n3 = 0.0; else { t3 *= t3; n3 = t3 * t3 * ngrad(gi3, x3, y3, z3); }
+  return 32.0 * (n0 + n1 + n2 + n3);
+}
+
+__device__ __forceinline__ double fractal3(double x, double y, double z, unsigned octaves) {  // :221-237
+  double output = 0.0, denom = 0.0, frequency = 1.0, amplitude = 1.0;
+  for (unsigned o = 0; o < octaves; o++) {
+    output += amplitude * simplex3(x * frequency, y * frequency, z * frequency);
+    denom += amplitude;
+    frequency *= 2.0;
+    amplitude *= 0.5;
+  }
+  return output / denom;
+}
+
+__device__ __forceinline__ void jitter_3d(const DPat& p, double x, double y, double z, double& ox, double& oy, double& oz) {  // :31-52
+  double nx, ny, nz;
+  if (p.noise_kind == 0) {
+    nx = simplex3(x, y, z) * p.scale;
+    ny = simplex3(x, y, z + 1.0) * p.scale;
+    nz = simplex3(x, y, z + 2.0) * p.scale;
+  } else {
+    nx = fractal3(x, y, z, p.octaves) * p.scale;
+    ny = fractal3(x, y, z + 1.0, p.octaves) * p.scale;
+    nz = fractal3(x, y, z + 2.0, p.octaves) * p.scale;
+  }
+  ox = x + nx; oy = y + ny; oz = z + nz;
+}
+
+// ---- Pattern::color_at (src/material.rs:164-302) as an explicit-stack walk of the node array ------------
+struct PFrame {
+  int node, stage;
+  double px, py, pz, pw, frac;
+  double lr, lg, lb;
+};
+
+__device__ __noinline__ void pattern_color(const DScene& S, int root, double px, double py, double pz, double pw, double& r, double& g, double& b) {
+  PFrame fr[8];  // RTC_MAX_PATTERN_DEPTH, validated at scene creation
+  int sp = 0;
+  int node = root;
+  for (;;) {
+    // ---- descend until a colour is known
+    for (;;) {
+      const DPat& p = S.pats[node];
+      if (p.tag == 0) { r = px; g = py; b = pz; break; }
+      if (p.tag == 1) { r = p.color[0]; g = p.color[1]; b = p.color[2]; break; }
+      if (p.tag == 2) {
+        if (p.kind == 1) {  // JitterKind::Point :218-221
+          double nx, ny, nz;
+          jitter_3d(p, px, py, pz, nx, ny, nz);
+          px = nx; py = ny; pz = nz; pw = 1.0;
+          node = p.left;
+        } else {  // JitterKind::Color :209-217
+          fr[sp].node = node; fr[sp].stage = 2; sp++;
+          node = p.left;
+        }
+        continue;
+      }
+      // Mixture: point = transform_inv * point (:181-183)
+      {
+        const double* m = p.m;
+        double x = m[0] * px + m[1] * py + m[2] * pz + m[3] * pw;
+        double y = m[4] * px + m[5] * py + m[6] * pz + m[7] * pw;
+        double z = m[8] * px + m[9] * py + m[10] * pz + m[11] * pw;
+        double w = m[12] * px + m[13] * py + m[14] * pz + m[15] * pw;
+        px = x; py = y; pz = z; pw = w;
+      }
+      if (p.kind == 1) {  // Checkers :258-268
+        int xi = as_i32(floor(px)), yi = as_i32(floor(py)), zi = as_i32(floor(pz));
+        node = (wadd(wadd(xi, yi), zi) % 2 == 0) ? p.left : p.right;
+      } else if (p.kind == 3) {  // Ring :278-284
+        node = (as_i32(floor(sqrt(px * px + pz * pz))) % 2 == 0) ? p.left : p.right;
+      } else if (p.kind == 5) {  // Stripes :293-299
+        node = (as_i32(floor(px)) % 2 == 0) ? p.left : p.right;
+      } else {  // Blend / RingGradient / Gradient: both children
+        double frac = 0.0;
+        if (p.kind == 2) { double d = sqrt(px * px + py * py + pz * pz); frac = d - floor(d); }  // :269-277
+        else if (p.kind == 4) frac = px - floor(px);                                             // :285-292
+        fr[sp].node = node; fr[sp].stage = 0; fr[sp].px = px; fr[sp].py = py; fr[sp].pz = pz; fr[sp].pw = pw; fr[sp].frac = frac;
+        sp++;
+        node = p.left;
+      }
+    }
+    // ---- ascend
+    bool again = false;
+    while (sp > 0) {
+      PFrame& f = fr[sp - 1];
+      const DPat& p = S.pats[f.node];
+      if (f.stage == 2) {
+        double nr, ng, nb;
+        jitter_3d(p, r, g, b, nr, ng, nb);
+        r = nr; g = ng; b = nb;
+        sp--;
+      } else if (f.stage == 0) {
+        f.lr = r; f.lg = g; f.lb = b; f.stage = 1;
+        px = f.px; py = f.py; pz = f.pz; pw = f.pw;
+        node = p.right;
+        again = true;
+        break;
+      } else {
+        if (p.kind == 0) { r = (f.lr + r) * 0.5; g = (f.lg + g) * 0.5; b = (f.lb + b) * 0.5; }  // Color::avg
+        else { r = f.lr + ((r - f.lr) * f.frac); g = f.lg + ((g - f.lg) * f.frac); b = f.lb + ((b - f.lb) * f.frac); }
+        sp--;
+      }
+    }
+    if (!again) return;
+  }
+}
+
+// ---- hit state (Intersection::prepare_state, src/intersection.rs:50-121) --------------------------------
+struct State {
+  double px, py, pz;     // over_point
+  double ux, uy, uz;     // under_point
+  double nx, ny, nz;     // normal (flipped when inside)
+  double ex, ey, ez;     // eye
+  double rx, ry, rz;     // reflect
+};
+
+// Geometry::normal (src/shape.rs:887-946) in object space
+__device__ __forceinline__ void local_normal(const DScene& S, const DPrim& P, double x, double y, double z, double u, double v, double& nx, double& ny, double& nz) {
+  switch (P.geom) {
+    case 0: nx = x; ny = y; nz = z; return;
+    case 1: nx = 0.0; ny = 1.0; nz = 0.0; return;
+    case 2: {
+      double xa = fabs(x), ya = fabs(y), za = fabs(z);
+      double mx = rmax(rmax(xa, ya), za);
+      if (mx == xa) { nx = x; ny = 0.0; nz = 0.0; }
+      else if (mx == ya) { nx = 0.0; ny = y; nz = 0.0; }
+      else { nx = 0.0; ny = 0.0; nz = z; }
+      return;
+    }
+    case 3:
+    case 4: {
+      double mn = S.limits[2 * P.data], mxl = S.limits[2 * P.data + 1];
+      double dist = x * x + z * z;
+      if (dist < 1.0 && y >= mxl - EPS) { nx = 0.0; ny = 1.0; nz = 0.0; return; }
+      if (dist < 1.0 && y <= mn + EPS) { nx = 0.0; ny = -1.0; nz = 0.0; return; }
+      if (P.geom == 3) { nx = x; ny = 0.0; nz = z; return; }
+      double yy = sqrt(dist);
+      if (y > 0.0) yy = -yy;
+      nx = x; ny = yy; nz = z;
+      return;
+    }
+    case 5: {
+      const double* n = S.tri_nrm + 9 * P.data;
+      nx = n[0]; ny = n[1]; nz = n[2];
+      return;
+    }
+    default: {  // *n2 * u + *n3 * v + *n1 * (1.0 - u - v)
+      const double* n = S.tri_nrm + 9 * P.data;
+      double w = 1.0 - u - v;
+      nx = n[3] * u + n[6] * v + n[0] * w;
+      ny = n[4] * u + n[7] * v + n[1] * w;
+      nz = n[5] * u + n[8] * v + n[2] * w;
+      return;
+    }
+  }
+}
+
+__device__ __forceinline__ void prepare_state(const DScene& S, const DPrim& P, const Ray& r, double t, double u, double v, State& st) {
+  // point = ray.position(t); eye = -direction
+  double qx = r.ox + r.dx * t, qy = r.oy + r.dy * t, qz = r.oz + r.dz * t;
+  st.ex = -r.dx; st.ey = -r.dy; st.ez = -r.dz;
+  // Shape::normal (src/shape.rs:419-427)
+  const double* m = S.xf_inv + 12 * P.xform;
+  double sx = m[0] * qx + m[1] * qy + m[2] * qz + m[3] * 1.0;
+  double sy = m[4] * qx + m[5] * qy + m[6] * qz + m[7] * 1.0;
+  double sz = m[8] * qx + m[9] * qy + m[10] * qz + m[11] * 1.0;
+  double lx, ly, lz;
+  local_normal(S, P, sx, sy, sz, u, v, lx, ly, lz);
+  // transform_inv_tsp * n: row r of the transpose = column r of transform_inv; the w term is (+-0)*0
+  double wx = m[0] * lx + m[4] * ly + m[8] * lz + 0.0;
+  double wy = m[1] * lx + m[5] * ly + m[9] * lz + 0.0;
+  double wz = m[2] * lx + m[6] * ly + m[10] * lz + 0.0;
+  double mag = sqrt(wx * wx + wy * wy + wz * wz);
+  double nx = wx / mag, ny = wy / mag, nz = wz / mag;
+  if (nx * st.ex + ny * st.ey + nz * st.ez < 0.0) { nx = -nx; ny = -ny; nz = -nz; }
+  st.nx = nx; st.ny = ny; st.nz = nz;
+  st.px = qx + nx * EPS; st.py = qy + ny * EPS; st.pz = qz + nz * EPS;
+  st.ux = qx - nx * EPS; st.uy = qy - ny * EPS; st.uz = qz - nz * EPS;
+  // reflect = direction - normal * (2 * direction.dot(normal))
+  double dn = 2.0 * (r.dx * nx + r.dy * ny + r.dz * nz);
+  st.rx = r.dx - nx * dn; st.ry = r.dy - ny * dn; st.rz = r.dz - nz * dn;
+}
+
+// schlick (src/intersection.rs:24-39)
+__device__ __forceinline__ double schlick(const State& st, double n1, double n2) {
+  double c = st.ex * st.nx + st.ey * st.ny + st.ez * st.nz;
+  if (n1 > n2) {
+    double n = n1 / n2;
+    double sin2_t = n * n * (1.0 - c * c);
+    if (sin2_t > 1.0) return 1.0;
+    c = sqrt(1.0 - sin2_t);
+  }
+  double q = (n1 - n2) / (n1 + n2);
+  double r0 = q * q;
+  double x = 1.0 - c;
+  double x5 = x * ((x * x) * (x * x));
+  return r0 + (1.0 - r0) * x5;
+}
+
+__device__ __forceinline__ void reset_closest(Trav& T, int mode) {
+  T.mode = mode;
+  T.tlo = 0.0; T.thi = DINF;
+  T.best_t = DINF; T.best_prim = 0x7fffffff; T.best_k = 0; T.best_klast = 0; T.best_u = 0.0; T.best_v = 0.0;
+  T.shadowed = 0; T.dist = 0.0;
+}
+
+struct Pending {
+  double ox, oy, oz, dx, dy, dz, weight;
+  int fuel, kind;
+};
+
+// Camera::ray_at_pixel (src/camera.rs:39-55)
+__device__ __forceinline__ Ray camera_ray(const DCamera& cam, uint64_t i) {
+  uint64_t x = i % cam.hsize, y = i / cam.hsize;
+  double xoffset = ((double)x + 0.5) * cam.pixel_size;
+  double yoffset = ((double)y + 0.5) * cam.pixel_size;
+  double world_x = cam.half_width - xoffset;
+  double world_y = cam.half_height - yoffset;
+  const double* m = cam.inv;
+  double px = m[0] * world_x + m[1] * world_y + m[2] * -1.0 + m[3] * 1.0;
+  double py = m[4] * world_x + m[5] * world_y + m[6] * -1.0 + m[7] * 1.0;
+  double pz = m[8] * world_x + m[9] * world_y + m[10] * -1.0 + m[11] * 1.0;
+  Ray r;
+  r.ox = m[3]; r.oy = m[7]; r.oz = m[11];
+  double dx = px - r.ox, dy = py - r.oy, dz = pz - r.oz;
+  double mag = sqrt(dx * dx + dy * dy + dz * dz);
+  r.dx = dx / mag; r.dy = dy / mag; r.dz = dz / mag;
+  return r;
+}
+
+}  // namespace
+
+// One lane = one pixel.  COUNT selects the variant that publishes work counters.
+template <bool COUNT>
+__global__ void __launch_bounds__(256) rtc_trace_kernel(DScene S, DCamera cam, DPixelMap pm, int fuel0, double* __restrict__ rgb, double* __restrict__ hit_t,
+                                                        int* __restrict__ hit_prim, int* __restrict__ hit_k, DStats* __restrict__ stats) {
+  __shared__ int lds_stack[RTC_BVH_STACK * 256];
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int* stack = lds_stack + threadIdx.x;
+  const int stride = 256;
+  Counters C = {0, 0, 0, 0, 0};
+  unsigned n_primary = 0, n_shadow = 0, n_reflect = 0, n_refract = 0, n_container = 0;
+
+  if (q < pm.n) {
+    Ray ray;
+    if (pm.mode == 3) {
+      const double* rr = pm.rays + 6 * q;
+      ray.ox = rr[0]; ray.oy = rr[1]; ray.oz = rr[2]; ray.dx = rr[3]; ray.dy = rr[4]; ray.dz = rr[5];
+    } else {
+      uint64_t i;
+      if (pm.mode == 0) i = pm.first + q;
+      else if (pm.mode == 1) i = pm.indices[q];
+      else i = ((uint64_t)pm.row_first + (q / cam.hsize) * pm.row_step) * cam.hsize + (q % cam.hsize);
+      ray = camera_ray(cam, i);
+    }
+
+    Pending pend[RTC_MAX_FUEL];
+    int np = 0;
+    double acc_r = 0.0, acc_g = 0.0, acc_b = 0.0;
+    double weight = 1.0;
+    int fuel = fuel0;
+    int kind = 0;
+    bool first = true;
+    const double L = (double)S.n_lights;
+
+    for (;;) {
+      if (kind == 0) n_primary++; else if (kind == 1) n_reflect++; else n_refract++;
+      Trav T;
+      reset_closest(T, MODE_CLOSEST);
+      traverse(S, ray, T, C, stack, stride);
+      bool did_hit = T.best_prim != 0x7fffffff;
+      if (first) {
+        first = false;
+        if (hit_t) {
+          hit_t[q] = did_hit ? T.best_t : 0.0;
+          hit_prim[q] = did_hit ? T.best_prim : -1;
+          hit_k[q] = did_hit ? T.best_k : 0;
+        }
+      }
+      if (did_hit) {
+        const DPrim P = S.prims[T.best_prim];
+        const double* M = S.mat + 8 * P.mat;
+        const double ambient = M[0], diffuse = M[1], specular = M[2], shininess = M[3], reflective = M[4], transparency = M[5];
+        State st;
+        prepare_state(S, P, ray, T.best_t, T.best_u, T.best_v, st);
+
+        // n1 / n2 / reflectance are only consumed when the surface is transparent (src/world.rs:70-78, :110)
+        double n1 = 1.0, n2 = 1.0;
+        if (transparency != 0.0) {
+          n_container++;
+          Trav K;
+          K.mode = MODE_CONTAINERS;
+          K.tlo = -DINF; K.thi = T.best_t;
+          K.h_t = T.best_t; K.h_prim = T.best_prim; K.h_klast = T.best_klast;
+          K.c1_prim = -1; K.c2_prim = -1; K.c1_t = 0.0; K.c2_t = 0.0; K.c1_ri = 1.0; K.c2_ri = 1.0;
+          K.shadowed = 0;
+          traverse(S, ray, K, C, stack, stride);
+          if (K.c1_prim >= 0) n1 = K.c1_ri;
+          if (K.c2_prim >= 0) n2 = K.c2_ri;
+        }
+
+        // Pattern::color_at(material_inv * over_point) — identical for every light (src/shape.rs:437)
+        double cr, cg, cb;
+        {
+          const double* mi = S.xf_matinv + 16 * P.xform;
+          double x = mi[0] * st.px + mi[1] * st.py + mi[2] * st.pz + mi[3] * 1.0;
+          double y = mi[4] * st.px + mi[5] * st.py + mi[6] * st.pz + mi[7] * 1.0;
+          double z = mi[8] * st.px + mi[9] * st.py + mi[10] * st.pz + mi[11] * 1.0;
+          double w = mi[12] * st.px + mi[13] * st.py + mi[14] * st.pz + mi[15] * 1.0;
+          const DPat& root = S.pats[S.mat_pattern[P.mat]];
+          if (root.tag == 1) { cr = root.color[0]; cg = root.color[1]; cb = root.color[2]; }
+          else pattern_color(S, S.mat_pattern[P.mat], x, y, z, w, cr, cg, cb);
+        }
+
+        // World::shade_hit (src/world.rs:50-82): per light, shadow test + Phong (src/shape.rs:429-462)
+        double sr = 0.0, sg = 0.0, sb = 0.0;
+        for (int l = 0; l < S.n_lights; l++) {
+          const double* LG = S.lights + 6 * l;
+          double vx = LG[3] - st.px, vy = LG[4] - st.py, vz = LG[5] - st.pz;
+          double distance = sqrt(vx * vx + vy * vy + vz * vz);
+          Ray sray;
+          sray.ox = st.px; sray.oy = st.py; sray.oz = st.pz;
+          sray.dx = vx / distance; sray.dy = vy / distance; sray.dz = vz / distance;
+          n_shadow++;
+          Trav Sh;
+          reset_closest(Sh, S.all_cast_shadow ? MODE_SHADOW_ANY : MODE_SHADOW_CLOSEST);
+          Sh.dist = distance;
+          if (S.all_cast_shadow) Sh.thi = distance;
+          traverse(S, sray, Sh, C, stack, stride);
+          bool shadowed;
+          if (S.all_cast_shadow) shadowed = Sh.shadowed != 0;
+          else shadowed = (Sh.best_prim != 0x7fffffff) && (S.prims[Sh.best_prim].flags & 1u) && (Sh.best_t < distance);
+
+          double er = cr * LG[0], eg = cg * LG[1], eb = cb * LG[2];  // effective_color
+          double lr = er * ambient, lg = eg * ambient, lb = eb * ambient;
+          // light vector: (light.origin - point).normalize() — same numbers as the shadow ray direction
+          double ldn = sray.dx * st.nx + sray.dy * st.ny + sray.dz * st.nz;
+          double dr = 0.0, dg = 0.0, db = 0.0, pr = 0.0, pg = 0.0, pb = 0.0;
+          if (!shadowed && ldn >= 0.0) {
+            dr = er * diffuse * ldn; dg = eg * diffuse * ldn; db = eb * diffuse * ldn;
+            // reflect = (-light).reflect(normal)
+            double mlx = -sray.dx, mly = -sray.dy, mlz = -sray.dz;
+            double d2 = 2.0 * (mlx * st.nx + mly * st.ny + mlz * st.nz);
+            double rfx = mlx - st.nx * d2, rfy = mly - st.ny * d2, rfz = mlz - st.nz * d2;
+            double rde = rfx * st.ex + rfy * st.ey + rfz * st.ez;
+            if (rde > 0.0) {
+              double f = pow(rde, shininess);
+              pr = LG[0] * specular * f; pg = LG[1] * specular * f; pb = LG[2] * specular * f;
+            }
+          }
+          sr += (lr + dr) + pr; sg += (lg + dg) + pg; sb += (lb + db) + pb;
+        }
+        acc_r += weight * sr; acc_g += weight * sg; acc_b += weight * sb;
+
+        // reflected_color / refracted_color (src/world.rs:84-132), once per light in the reference -> factor L
+        if (fuel > 0) {
+          bool do_refl = reflective != 0.0;
+          bool do_refr = transparency != 0.0;
+          double wr = weight * L * reflective, wt = weight * L * transparency;
+          if (reflective > 0.0 && transparency > 0.0) {
+            double R = schlick(st, n1, n2);
+            wr *= R;
+            wt *= (1.0 - R);
+          }
+          double tdx = 0.0, tdy = 0.0, tdz = 0.0;
+          if (do_refr) {
+            double n_ratio = n1 / n2;
+            double cos_i = st.ex * st.nx + st.ey * st.ny + st.ez * st.nz;
+            double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
+            if (sin2_t > 1.0) do_refr = false;
+            else {
+              double cos_t = sqrt(1.0 - sin2_t);
+              double kk = n_ratio * cos_i - cos_t;
+              tdx = st.nx * kk - st.ex * n_ratio; tdy = st.ny * kk - st.ey * n_ratio; tdz = st.nz * kk - st.ez * n_ratio;
+            }
+          }
+          if (do_refr) {
+            Pending& p = pend[np++];
+            p.ox = st.ux; p.oy = st.uy; p.oz = st.uz; p.dx = tdx; p.dy = tdy; p.dz = tdz;
+            p.weight = wt; p.fuel = fuel - 1; p.kind = 2;
+          }
+          if (do_refl) {
+            Pending& p = pend[np++];
+            p.ox = st.px; p.oy = st.py; p.oz = st.pz; p.dx = st.rx; p.dy = st.ry; p.dz = st.rz;
+            p.weight = wr; p.fuel = fuel - 1; p.kind = 1;
+          }
+        }
+      }
+      if (np == 0) break;
+      const Pending& p = pend[--np];
+      ray.ox = p.ox; ray.oy = p.oy; ray.oz = p.oz; ray.dx = p.dx; ray.dy = p.dy; ray.dz = p.dz;
+      weight = p.weight; fuel = p.fuel; kind = p.kind;
+    }
+    rgb[3 * q + 0] = acc_r;
+    rgb[3 * q + 1] = acc_g;
+    rgb[3 * q + 2] = acc_b;
+  }
+
+  if (COUNT || true) {
+    // nan_ts must always be published (error reporting); the rest only in the counting variant
+    if (C.nan_ts) atomicAdd(&stats->nan_ts, (unsigned long long)C.nan_ts);
+  }
+  if (COUNT) {
+    atomicAdd(&stats->rays_primary, (unsigned long long)n_primary);
+    atomicAdd(&stats->rays_shadow, (unsigned long long)n_shadow);
+    atomicAdd(&stats->rays_reflect, (unsigned long long)n_reflect);
+    atomicAdd(&stats->rays_refract, (unsigned long long)n_refract);
+    atomicAdd(&stats->rays_container, (unsigned long long)n_container);
+    atomicAdd(&stats->accel_nodes, (unsigned long long)C.accel_nodes);
+    atomicAdd(&stats->group_tests, (unsigned long long)C.group_tests);
+    atomicAdd(&stats->tri_tests, (unsigned long long)C.tri_tests);
+    atomicAdd(&stats->analytic_tests, (unsigned long long)C.analytic_tests);
+  }
+}
+
+// ---- host-callable launcher (C++ linkage, used by rtc_scene.cpp) ------------------------------------------
+void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
+                      DStats* stats, bool count, hipStream_t stream) {
+  if (pm.n == 0) return;
+  dim3 block(256);
+  dim3 grid((unsigned)((pm.n + 255) / 256));
+  if (count) hipLaunchKernelGGL(rtc_trace_kernel<true>, grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats);
+  else hipLaunchKernelGGL(rtc_trace_kernel<false>, grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats);
+}

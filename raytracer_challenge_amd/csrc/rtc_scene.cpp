@@ -1,0 +1,284 @@
+// rtc_scene.cpp — the rtc.h C ABI: validates a flattened scene, builds the traversal program + accelerator,
+// uploads SoA buffers to HBM and launches the trace kernels.  There is no CPU execution path in this file:
+// every entry point that computes pixels needs a HIP device and fails with RTC_ERR_DEVICE otherwise.
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/rtc.h"
+#include "device_scene.h"
+#include "scene_build.hpp"
+
+void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
+                      DStats* stats, bool count, hipStream_t stream);
+
+static thread_local std::string g_rtc_err;
+static int rtc_fail(int code, const std::string& m) {
+  g_rtc_err = m;
+  return code;
+}
+#define HIP_OK(expr)                                                                                     \
+  do {                                                                                                   \
+    hipError_t e_ = (expr);                                                                              \
+    if (e_ != hipSuccess) return rtc_fail(RTC_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+struct rtc_scene {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<void*> allocs;
+  uint64_t bytes = 0;
+  DScene d{};
+  DStats* d_stats = nullptr;
+  // scratch output buffers (grown on demand)
+  double* d_rgb = nullptr;
+  double* d_hit_t = nullptr;
+  int* d_hit_prim = nullptr;
+  int* d_hit_k = nullptr;
+  uint64_t* d_idx = nullptr;
+  double* d_rays = nullptr;
+  uint64_t cap_px = 0, cap_idx = 0, cap_rays = 0;
+  int bvh_depth = 0;
+  uint32_t n_bvh_nodes = 0, n_mesh_tris = 0;
+
+  template <class T>
+  int upload(const std::vector<T>& v, const T** out) {
+    *out = nullptr;
+    if (v.empty()) return RTC_OK;
+    void* p = nullptr;
+    HIP_OK(hipMalloc(&p, v.size() * sizeof(T)));
+    allocs.push_back(p);
+    bytes += v.size() * sizeof(T);
+    HIP_OK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)p;
+    return RTC_OK;
+  }
+};
+
+namespace {
+
+int ensure_px(rtc_scene* s, uint64_t n, bool hits) {
+  if (n > s->cap_px) {
+    if (s->d_rgb) { (void)hipFree(s->d_rgb); (void)hipFree(s->d_hit_t); (void)hipFree(s->d_hit_prim); (void)hipFree(s->d_hit_k); }
+    s->d_rgb = nullptr; s->cap_px = 0;
+    HIP_OK(hipMalloc((void**)&s->d_rgb, n * 3 * sizeof(double)));
+    HIP_OK(hipMalloc((void**)&s->d_hit_t, n * sizeof(double)));
+    HIP_OK(hipMalloc((void**)&s->d_hit_prim, n * sizeof(int)));
+    HIP_OK(hipMalloc((void**)&s->d_hit_k, n * sizeof(int)));
+    s->cap_px = n;
+  }
+  (void)hits;
+  return RTC_OK;
+}
+
+void to_dcam(const rtc_camera& c, DCamera* d) {
+  d->hsize = c.hsize; d->vsize = c.vsize;
+  d->half_width = c.half_width; d->half_height = c.half_height; d->pixel_size = c.pixel_size;
+  std::memcpy(d->inv, c.transform_inv, sizeof(d->inv));
+}
+
+int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb, bool want_hits, rtc_stats* stats, bool count, bool sync) {
+  if (fuel < 0) fuel = 0;  // fuel <= 0 spawns nothing (src/world.rs:90,110)
+  if (fuel > RTC_MAX_FUEL) return rtc_fail(RTC_ERR_INVALID, "fuel exceeds RTC_MAX_FUEL");
+  HIP_OK(hipSetDevice(s->device));
+  HIP_OK(hipMemsetAsync(s->d_stats, 0, sizeof(DStats), s->stream));
+  HIP_OK(hipEventRecord(s->ev0, s->stream));
+  rtc_launch_trace(s->d, cam, pm, fuel, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipEventRecord(s->ev1, s->stream));
+  if (!sync && !stats) return RTC_OK;
+  HIP_OK(hipStreamSynchronize(s->stream));
+  DStats h;
+  HIP_OK(hipMemcpy(&h, s->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+  if (stats) {
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    std::memset(stats, 0, sizeof(*stats));
+    stats->pixels = pm.n;
+    stats->rays_primary = h.rays_primary; stats->rays_shadow = h.rays_shadow; stats->rays_reflect = h.rays_reflect; stats->rays_refract = h.rays_refract;
+    stats->rays_container = h.rays_container; stats->accel_nodes = h.accel_nodes; stats->group_tests = h.group_tests; stats->tri_tests = h.tri_tests;
+    stats->analytic_tests = h.analytic_tests; stats->nan_ts = h.nan_ts;
+    stats->kernel_ms = ms;
+    stats->n_launches = 1;
+  }
+  if (h.nan_ts) return rtc_fail(RTC_ERR_NAN, "a NaN intersection t was produced (the reference panics in Intersection::sort, src/intersection.rs:124)");
+  return RTC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rtc_last_error(void) { return g_rtc_err.c_str(); }
+
+int rtc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
+  if (!desc || !out) return rtc_fail(RTC_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  rtb::HostArrays H;
+  std::string err;
+  int rc = rtb::build_arrays(*desc, &H, &err);
+  if (rc != RTC_OK) return rtc_fail(rc, err);
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return rtc_fail(RTC_ERR_DEVICE, "no HIP device available (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return rtc_fail(RTC_ERR_DEVICE, "device index out of range");
+  HIP_OK(hipSetDevice(device));
+
+  std::unique_ptr<rtc_scene> s(new rtc_scene());
+  s->device = device;
+  HIP_OK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  HIP_OK(hipEventCreate(&s->ev0));
+  HIP_OK(hipEventCreate(&s->ev1));
+
+  DScene& d = s->d;
+#define UP(field)                                                       \
+  do {                                                                  \
+    int rc_ = s->upload(H.field, &d.field);                             \
+    if (rc_ != RTC_OK) { rtc_scene_destroy(s.release()); return rc_; } \
+  } while (0)
+  UP(ops); UP(group_box); UP(bvh); UP(mtri); UP(mtri_prim); UP(item_prim); UP(quirk_prim); UP(prims); UP(xf_inv); UP(xf_matinv); UP(limits);
+  UP(tri_geo); UP(tri_nrm); UP(mat); UP(mat_pattern); UP(pats); UP(lights);
+#undef UP
+  d.n_ops = (int32_t)H.ops.size();
+  d.n_prims = (int32_t)H.prims.size();
+  d.n_lights = H.n_lights;
+  d.all_cast_shadow = H.all_cast_shadow;
+  s->bvh_depth = H.bvh_depth;
+  s->n_bvh_nodes = (uint32_t)H.bvh.size();
+  s->n_mesh_tris = (uint32_t)H.mtri_prim.size();
+  HIP_OK(hipMalloc((void**)&s->d_stats, sizeof(DStats)));
+  HIP_OK(hipMemset(s->d_stats, 0, sizeof(DStats)));
+  *out = s.release();
+  return RTC_OK;
+}
+
+void rtc_scene_destroy(rtc_scene* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  for (void* p : s->allocs) (void)hipFree(p);
+  if (s->d_stats) (void)hipFree(s->d_stats);
+  if (s->d_rgb) { (void)hipFree(s->d_rgb); (void)hipFree(s->d_hit_t); (void)hipFree(s->d_hit_prim); (void)hipFree(s->d_hit_k); }
+  if (s->d_idx) (void)hipFree(s->d_idx);
+  if (s->d_rays) (void)hipFree(s->d_rays);
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+uint64_t rtc_scene_device_bytes(const rtc_scene* s) { return s ? s->bytes : 0; }
+
+int rtc_render(rtc_scene* s, const rtc_camera* cam, int32_t fuel, const uint64_t* pixel_indices, uint64_t first, uint64_t n, double* rgb, rtc_hit* hits,
+               rtc_stats* stats) {
+  if (!s || !cam || (!rgb && n)) return rtc_fail(RTC_ERR_INVALID, "NULL argument");
+  if (cam->hsize == 0 || cam->vsize == 0) return rtc_fail(RTC_ERR_INVALID, "empty camera");
+  const uint64_t total = cam->hsize * cam->vsize;
+  if (!pixel_indices && first + n > total) return rtc_fail(RTC_ERR_INVALID, "pixel range exceeds the image");
+  if (n == 0) { if (stats) std::memset(stats, 0, sizeof(*stats)); return RTC_OK; }
+  HIP_OK(hipSetDevice(s->device));
+  int rc = ensure_px(s, n, hits != nullptr);
+  if (rc != RTC_OK) return rc;
+  DPixelMap pm{};
+  pm.n = n; pm.first = first; pm.mode = 0;
+  if (pixel_indices) {
+    for (uint64_t i = 0; i < n; i++)
+      if (pixel_indices[i] >= total) return rtc_fail(RTC_ERR_INVALID, "pixel index exceeds the image");
+    if (n > s->cap_idx) {
+      if (s->d_idx) (void)hipFree(s->d_idx);
+      s->d_idx = nullptr; s->cap_idx = 0;
+      HIP_OK(hipMalloc((void**)&s->d_idx, n * sizeof(uint64_t)));
+      s->cap_idx = n;
+    }
+    HIP_OK(hipMemcpyAsync(s->d_idx, pixel_indices, n * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
+    pm.mode = 1; pm.indices = s->d_idx;
+  }
+  DCamera dc;
+  to_dcam(*cam, &dc);
+  rc = run(s, dc, pm, fuel, s->d_rgb, hits != nullptr, stats, stats != nullptr, true);
+  if (rc != RTC_OK) return rc;
+  HIP_OK(hipMemcpy(rgb, s->d_rgb, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+  if (hits) {
+    std::vector<double> t(n);
+    std::vector<int> p(n), k(n);
+    HIP_OK(hipMemcpy(t.data(), s->d_hit_t, n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(p.data(), s->d_hit_prim, n * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(k.data(), s->d_hit_k, n * sizeof(int), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n; i++) hits[i] = {t[i], p[i], k[i]};
+  }
+  return RTC_OK;
+}
+
+int rtc_render_rows_device(rtc_scene* s, const rtc_camera* cam, int32_t fuel, uint32_t row_first, uint32_t row_step, uint32_t n_rows, double* rgb_dev,
+                           rtc_stats* stats, int count_stats, int sync) {
+  if (!s || !cam || (!rgb_dev && n_rows)) return rtc_fail(RTC_ERR_INVALID, "NULL argument");
+  if (row_step == 0) return rtc_fail(RTC_ERR_INVALID, "row_step must be >= 1");
+  if (n_rows && (uint64_t)row_first + (uint64_t)(n_rows - 1) * row_step >= cam->vsize) return rtc_fail(RTC_ERR_INVALID, "rows exceed the image");
+  DPixelMap pm{};
+  pm.n = (uint64_t)n_rows * cam->hsize;
+  pm.mode = 2; pm.row_first = row_first; pm.row_step = row_step;
+  if (pm.n == 0) { if (stats) std::memset(stats, 0, sizeof(*stats)); return RTC_OK; }
+  DCamera dc;
+  to_dcam(*cam, &dc);
+  return run(s, dc, pm, fuel, rgb_dev, false, stats, count_stats != 0, sync != 0);
+}
+
+int rtc_trace_rays(rtc_scene* s, const double* rays, uint64_t n, int32_t fuel, double* rgb, rtc_hit* hits, rtc_stats* stats) {
+  if (!s || (!rays && n) || (!rgb && n)) return rtc_fail(RTC_ERR_INVALID, "NULL argument");
+  if (n == 0) return RTC_OK;
+  HIP_OK(hipSetDevice(s->device));
+  int rc = ensure_px(s, n, hits != nullptr);
+  if (rc != RTC_OK) return rc;
+  if (n > s->cap_rays) {
+    if (s->d_rays) (void)hipFree(s->d_rays);
+    s->d_rays = nullptr; s->cap_rays = 0;
+    HIP_OK(hipMalloc((void**)&s->d_rays, n * 6 * sizeof(double)));
+    s->cap_rays = n;
+  }
+  HIP_OK(hipMemcpyAsync(s->d_rays, rays, n * 6 * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  DPixelMap pm{};
+  pm.n = n; pm.mode = 3; pm.rays = s->d_rays;
+  DCamera dc{};
+  dc.hsize = 1; dc.vsize = 1;
+  rc = run(s, dc, pm, fuel, s->d_rgb, hits != nullptr, stats, stats != nullptr, true);
+  if (rc != RTC_OK) return rc;
+  HIP_OK(hipMemcpy(rgb, s->d_rgb, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+  if (hits) {
+    std::vector<double> t(n);
+    std::vector<int> p(n), k(n);
+    HIP_OK(hipMemcpy(t.data(), s->d_hit_t, n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(p.data(), s->d_hit_prim, n * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(k.data(), s->d_hit_k, n * sizeof(int), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n; i++) hits[i] = {t[i], p[i], k[i]};
+  }
+  return RTC_OK;
+}
+
+int rtc_scene_sync(rtc_scene* s) {
+  if (!s) return rtc_fail(RTC_ERR_INVALID, "NULL scene");
+  HIP_OK(hipSetDevice(s->device));
+  HIP_OK(hipStreamSynchronize(s->stream));
+  return RTC_OK;
+}
+
+// Accelerator facts for reports (not part of the reference-facing surface).
+void rtc_scene_accel_info(const rtc_scene* s, uint32_t* n_ops, uint32_t* n_bvh_nodes, uint32_t* n_mesh_tris, uint32_t* bvh_depth) {
+  if (n_ops) *n_ops = s ? (uint32_t)s->d.n_ops : 0;
+  if (n_bvh_nodes) *n_bvh_nodes = s ? s->n_bvh_nodes : 0;
+  if (n_mesh_tris) *n_mesh_tris = s ? s->n_mesh_tris : 0;
+  if (bvh_depth) *bvh_depth = s ? (uint32_t)s->bvh_depth : 0;
+}
+
+}  // extern "C"

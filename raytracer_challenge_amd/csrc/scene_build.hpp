@@ -1,0 +1,314 @@
+// scene_build.hpp — pure host code (no HIP calls): validates an rtc_scene_desc and turns it into the arrays of
+// device_scene.h: the traversal program, the exact group boxes, the accelerator BVHs and the SoA tables.
+// rtc_scene.cpp uploads these arrays verbatim; tests/cpu_emu runs the kernel source on them on the CPU.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rtc.h"
+#include "bvh_build.hpp"
+#include "device_scene.h"
+#include "host_scene.hpp"
+
+namespace rtb {
+
+
+struct ProgramBuilder {
+  const rtc_scene_desc& D;
+  std::vector<DOp> ops;
+  std::vector<double> group_box;
+  std::vector<DBvhNode> bvh_nodes;
+  std::vector<double> mtri;
+  std::vector<int32_t> mtri_prim, item_prim, quirk_prim;
+  int max_depth = 0;
+  std::string error;
+  int status = RTC_OK;
+
+  static constexpr size_t kMinAccel = 6;  // fewer bounded children than this stay a linear list
+
+  bool local_bounds(const rtc_prim& p, double lo[3], double hi[3]) const {
+    // bounds of every point the exact test can report, in object space (tighter than Geometry::bbox for open
+    // cylinders, whose walls only exist for min < y < max: src/shape.rs:745,756)
+    switch (p.geometry) {
+      case RTC_SPHERE:
+      case RTC_CUBE:
+        for (int a = 0; a < 3; a++) { lo[a] = -1.0; hi[a] = 1.0; }
+        return true;
+      case RTC_PLANE: return false;
+      case RTC_CYLINDER:
+      case RTC_CONE: {
+        double mn = D.limits[2 * p.data], mx = D.limits[2 * p.data + 1];
+        if (!std::isfinite(mn) || !std::isfinite(mx)) return false;
+        double r = p.geometry == RTC_CYLINDER ? 1.0 : std::fmax(std::fabs(mn), std::fabs(mx));
+        lo[0] = -r; hi[0] = r; lo[1] = std::fmin(mn, mx); hi[1] = std::fmax(mn, mx); lo[2] = -r; hi[2] = r;
+        return true;
+      }
+      default: {
+        const double* g = D.tri_p1e1e2 + 9 * (size_t)p.data;
+        for (int a = 0; a < 3; a++) {
+          double v0 = g[a], v1 = g[a] + g[3 + a], v2 = g[a] + g[6 + a];
+          lo[a] = std::fmin(v0, std::fmin(v1, v2));
+          hi[a] = std::fmax(v0, std::fmax(v1, v2));
+          if (!std::isfinite(lo[a]) || !std::isfinite(hi[a])) return false;
+        }
+        return true;
+      }
+    }
+  }
+
+  bool world_bounds(const rtc_prim& p, bvh::Item* out) const {
+    double lo[3], hi[3];
+    if (!local_bounds(p, lo, hi)) return false;
+    rth::M4 inv = rth::M4::from(D.xforms[p.xform].transform_inv), fwd;
+    if (!inv.invert(&fwd)) return false;
+    for (int a = 0; a < 3; a++) { out->lo[a] = rth::kInf; out->hi[a] = -rth::kInf; }
+    for (int k = 0; k < 8; k++) {
+      rth::V4 c = fwd.apply(rth::pt((k & 4) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], (k & 1) ? hi[2] : lo[2]));
+      double q[3] = {c.x, c.y, c.z};
+      for (int a = 0; a < 3; a++) {
+        if (!std::isfinite(q[a])) return false;
+        out->lo[a] = std::fmin(out->lo[a], q[a]);
+        out->hi[a] = std::fmax(out->hi[a], q[a]);
+      }
+    }
+    // the forward matrix is a numerical inverse of an inverse: widen by its conditioning-independent slop
+    for (int a = 0; a < 3; a++) {
+      double pad = 1e-9 * (std::fabs(out->lo[a]) + std::fabs(out->hi[a]) + (out->hi[a] - out->lo[a]));
+      out->lo[a] -= pad;
+      out->hi[a] += pad;
+    }
+    return true;
+  }
+
+  int32_t build_tree(const std::vector<bvh::Item>& items, std::vector<uint32_t>& order, uint32_t base) {
+    int depth = 0;
+    size_t n0 = bvh_nodes.size(), o0 = order.size();
+    int32_t root = bvh::build(items, bvh_nodes, order, base, &depth);
+    if (depth > RTC_BVH_STACK - 2) {
+      bvh_nodes.resize(n0);
+      order.resize(o0);
+      root = bvh::build(items, bvh_nodes, order, base, &depth, true);
+    }
+    max_depth = std::max(max_depth, depth);
+    return root;
+  }
+
+  // Emits the program for the children list nodes[b, e) of one group (or of the world).
+  bool emit(uint32_t b, uint32_t e) {
+    std::vector<uint32_t> prim_kids, group_kids;
+    for (uint32_t i = b; i < e;) {
+      const rtc_node& n = D.nodes[i];
+      if (n.skip <= (int32_t)i || (uint32_t)n.skip > e) { error = "node skip out of range"; status = RTC_ERR_INVALID; return false; }
+      if (n.kind == RTC_NODE_PRIM) prim_kids.push_back(i); else group_kids.push_back(i);
+      i = (uint32_t)n.skip;
+    }
+    // 1. triangles that share one matrix -> object-space mesh BVHs
+    std::map<int32_t, std::vector<int32_t>> meshes;
+    std::vector<int32_t> rest;
+    for (uint32_t i : prim_kids) {
+      const rtc_prim& p = D.prims[D.nodes[i].ref];
+      if (p.geometry >= RTC_TRIANGLE) meshes[p.xform].push_back(D.nodes[i].ref); else rest.push_back(D.nodes[i].ref);
+    }
+    for (auto& kv : meshes) {
+      std::vector<bvh::Item> items;
+      std::vector<int32_t> ids;
+      for (int32_t pi : kv.second) {
+        bvh::Item it;
+        if (local_bounds(D.prims[pi], it.lo, it.hi)) { items.push_back(it); ids.push_back(pi); }
+        else rest.push_back(pi);
+      }
+      if (items.size() < kMinAccel) { for (int32_t pi : ids) rest.push_back(pi); continue; }
+      std::vector<uint32_t> order;
+      uint32_t base = (uint32_t)mtri_prim.size();
+      int32_t root = build_tree(items, order, base);
+      for (uint32_t k : order) {
+        int32_t pi = ids[k];
+        const double* g = D.tri_p1e1e2 + 9 * (size_t)D.prims[pi].data;
+        mtri.insert(mtri.end(), g, g + 9);
+        mtri_prim.push_back(pi);
+      }
+      ops.push_back({OP_MESH, root, kv.first, (int32_t)items.size()});
+    }
+    // 2. remaining bounded primitives -> one world-space BVH; unbounded ones stay linear
+    {
+      std::vector<bvh::Item> items;
+      std::vector<int32_t> ids, linear;
+      for (int32_t pi : rest) {
+        bvh::Item it;
+        if (world_bounds(D.prims[pi], &it)) { items.push_back(it); ids.push_back(pi); } else linear.push_back(pi);
+      }
+      if (items.size() < kMinAccel) { for (int32_t pi : ids) linear.push_back(pi); ids.clear(); items.clear(); }
+      std::sort(linear.begin(), linear.end());
+      for (int32_t pi : linear) ops.push_back({OP_PRIM, pi, 0, 0});
+      if (!items.empty()) {
+        std::vector<uint32_t> order;
+        uint32_t base = (uint32_t)item_prim.size();
+        int32_t root = build_tree(items, order, base);
+        for (uint32_t k : order) item_prim.push_back(ids[k]);
+        ops.push_back({OP_BVH, root, 0, (int32_t)items.size()});
+        int32_t q0 = (int32_t)quirk_prim.size();
+        for (int32_t pi : ids)
+          if (D.prims[pi].geometry == RTC_CUBE || D.prims[pi].geometry == RTC_CONE) quirk_prim.push_back(pi);
+        if ((int32_t)quirk_prim.size() > q0) ops.push_back({OP_QUIRK, q0, (int32_t)quirk_prim.size() - q0, 0});
+      }
+    }
+    // 3. child groups: exact reference box test, then their own program
+    for (uint32_t i : group_kids) {
+      const rtc_node& n = D.nodes[i];
+      if (n.kind != RTC_NODE_AGGREGATION) {
+        error = "CSG group kinds (Union/Intersection/Difference, src/shape.rs:161-178) are not supported on device yet";
+        status = RTC_ERR_UNSUPPORTED;
+        return false;
+      }
+      int32_t gi = (int32_t)(group_box.size() / 6);
+      group_box.insert(group_box.end(), n.bbox_min, n.bbox_min + 3);
+      group_box.insert(group_box.end(), n.bbox_max, n.bbox_max + 3);
+      size_t at = ops.size();
+      ops.push_back({OP_GROUP, gi, 0, 0});
+      if (!emit(i + 1, (uint32_t)n.skip)) return false;
+      ops[at].b = (int32_t)ops.size();
+    }
+    return true;
+  }
+};
+
+inline int validate(const rtc_scene_desc& D, std::string* err) {
+  auto bad = [&](const char* m) { *err = m; return RTC_ERR_INVALID; };
+  if (D.n_lights > 0 && !D.lights) return bad("lights is NULL");
+  for (uint32_t i = 0; i < D.n_prims; i++) {
+    const rtc_prim& p = D.prims[i];
+    if (p.geometry < RTC_SPHERE || p.geometry > RTC_SMOOTH_TRIANGLE) return bad("primitive geometry out of range");
+    if (p.material < 0 || (uint32_t)p.material >= D.n_materials) return bad("primitive material index out of range");
+    if (p.xform < 0 || (uint32_t)p.xform >= D.n_xforms) return bad("primitive xform index out of range");
+    if ((p.geometry == RTC_CYLINDER || p.geometry == RTC_CONE) && (p.data < 0 || (uint32_t)p.data >= D.n_limits)) return bad("limits index out of range");
+    if (p.geometry >= RTC_TRIANGLE && (p.data < 0 || (uint32_t)p.data >= D.n_tris)) return bad("triangle index out of range");
+  }
+  uint32_t seen = 0;
+  for (uint32_t i = 0; i < D.n_nodes; i++) {
+    const rtc_node& n = D.nodes[i];
+    if (n.kind == RTC_NODE_PRIM) {
+      if (n.ref != (int32_t)seen) return bad("primitive nodes must reference primitives in DFS order");
+      seen++;
+      if (n.skip != (int32_t)i + 1) return bad("primitive node skip must be index+1");
+    } else if (n.kind < RTC_NODE_UNION || n.kind > RTC_NODE_AGGREGATION) return bad("node kind out of range");
+    if (n.skip <= (int32_t)i || (uint32_t)n.skip > D.n_nodes) return bad("node skip out of range");
+  }
+  if (seen != D.n_prims) return bad("node array does not cover every primitive exactly once");
+  for (uint32_t i = 0; i < D.n_materials; i++)
+    if (D.materials[i].pattern < 0 || (uint32_t)D.materials[i].pattern >= D.n_pattern_nodes) return bad("material pattern index out of range");
+  // pattern nodes: children precede parents is not required; check indices + depth
+  std::vector<int> depth(D.n_pattern_nodes, 0);
+  for (uint32_t pass = 0; pass <= RTC_MAX_PATTERN_DEPTH + 1; pass++) {
+    bool changed = false;
+    for (uint32_t i = 0; i < D.n_pattern_nodes; i++) {
+      const rtc_pattern_node& p = D.pattern_nodes[i];
+      if (p.tag < RTC_PAT_DEBUG || p.tag > RTC_PAT_MIXTURE) return bad("pattern tag out of range");
+      int d = 1;
+      if (p.tag >= RTC_PAT_JITTER) {
+        if (p.left < 0 || (uint32_t)p.left >= D.n_pattern_nodes) return bad("pattern child out of range");
+        d = std::max(d, 1 + depth[p.left]);
+      }
+      if (p.tag == RTC_PAT_MIXTURE) {
+        if (p.right < 0 || (uint32_t)p.right >= D.n_pattern_nodes) return bad("pattern child out of range");
+        if (p.kind < RTC_MIX_BLEND || p.kind > RTC_MIX_STRIPES) return bad("mixture kind out of range");
+        d = std::max(d, 1 + depth[p.right]);
+      }
+      if (d != depth[i]) { depth[i] = d; changed = true; }
+      if (d > RTC_MAX_PATTERN_DEPTH) return bad("pattern tree deeper than RTC_MAX_PATTERN_DEPTH (or cyclic)");
+    }
+    if (!changed) break;
+  }
+  return RTC_OK;
+}
+
+
+// All arrays of one scene, host side.  `view()` gives a DScene whose pointers address these vectors.
+struct HostArrays {
+  std::vector<DOp> ops;
+  std::vector<double> group_box;
+  std::vector<DBvhNode> bvh;
+  std::vector<double> mtri;
+  std::vector<int32_t> mtri_prim, item_prim, quirk_prim;
+  std::vector<DPrim> prims;
+  std::vector<double> xf_inv, xf_matinv, limits, tri_geo, tri_nrm, mat;
+  std::vector<int32_t> mat_pattern;
+  std::vector<DPat> pats;
+  std::vector<double> lights;
+  int32_t n_lights = 0, all_cast_shadow = 1, bvh_depth = 0;
+
+  DScene view() const {
+    DScene d{};
+    d.ops = ops.data(); d.group_box = group_box.data(); d.bvh = bvh.data(); d.mtri = mtri.data(); d.mtri_prim = mtri_prim.data();
+    d.item_prim = item_prim.data(); d.quirk_prim = quirk_prim.data(); d.prims = prims.data(); d.xf_inv = xf_inv.data(); d.xf_matinv = xf_matinv.data(); d.limits = limits.data();
+    d.tri_geo = tri_geo.data(); d.tri_nrm = tri_nrm.data(); d.mat = mat.data(); d.mat_pattern = mat_pattern.data(); d.pats = pats.data();
+    d.lights = lights.data();
+    d.n_ops = (int32_t)ops.size(); d.n_prims = (int32_t)prims.size(); d.n_lights = n_lights; d.all_cast_shadow = all_cast_shadow;
+    return d;
+  }
+};
+
+// desc -> arrays.  Returns an RTC_* status; message in *err.
+inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err) {
+  int rc = validate(D, err);
+  if (rc != RTC_OK) return rc;
+  if (D.n_lights > 64) { *err = "more than 64 lights"; return RTC_ERR_INVALID; }
+  ProgramBuilder pb{D};
+  if (!pb.emit(0, D.n_nodes)) { *err = pb.error; return pb.status; }
+  H->prims.resize(D.n_prims);
+  H->all_cast_shadow = 1;
+  for (uint32_t i = 0; i < D.n_prims; i++) {
+    H->prims[i] = {D.prims[i].geometry, D.prims[i].flags, D.prims[i].material, D.prims[i].xform, D.prims[i].data, {0, 0, 0}};
+    if (!(D.prims[i].flags & RTC_FLAG_CASTS_SHADOW)) H->all_cast_shadow = 0;
+  }
+  H->xf_inv.resize((size_t)D.n_xforms * 12);
+  H->xf_matinv.resize((size_t)D.n_xforms * 16);
+  for (uint32_t i = 0; i < D.n_xforms; i++) {
+    std::memcpy(&H->xf_inv[(size_t)i * 12], D.xforms[i].transform_inv, 12 * sizeof(double));
+    std::memcpy(&H->xf_matinv[(size_t)i * 16], D.xforms[i].material_inv, 16 * sizeof(double));
+  }
+  H->limits.assign(D.limits, D.limits + (size_t)D.n_limits * 2);
+  H->tri_geo.assign(D.tri_p1e1e2, D.tri_p1e1e2 + (size_t)D.n_tris * 9);
+  H->tri_nrm.assign(D.tri_normals, D.tri_normals + (size_t)D.n_tris * 9);
+  H->mat.assign((size_t)D.n_materials * 8, 0.0);
+  H->mat_pattern.resize(D.n_materials);
+  for (uint32_t i = 0; i < D.n_materials; i++) {
+    const rtc_material& m = D.materials[i];
+    double* q = &H->mat[(size_t)i * 8];
+    q[0] = m.ambient; q[1] = m.diffuse; q[2] = m.specular; q[3] = m.shininess; q[4] = m.reflective; q[5] = m.transparency; q[6] = m.refractive_index;
+    H->mat_pattern[i] = m.pattern;
+  }
+  H->pats.resize(D.n_pattern_nodes);
+  for (uint32_t i = 0; i < D.n_pattern_nodes; i++) {
+    const rtc_pattern_node& p = D.pattern_nodes[i];
+    DPat& q = H->pats[i];
+    std::memset(&q, 0, sizeof(q));
+    q.tag = p.tag; q.kind = p.kind; q.noise_kind = p.noise_kind; q.octaves = p.octaves; q.left = p.left; q.right = p.right; q.scale = p.scale;
+    std::memcpy(q.color, p.color, sizeof(q.color));
+    std::memcpy(q.m, p.transform_inv, sizeof(q.m));
+  }
+  H->lights.resize((size_t)D.n_lights * 6);
+  for (uint32_t i = 0; i < D.n_lights; i++) {
+    std::memcpy(&H->lights[(size_t)i * 6], D.lights[i].intensity, 3 * sizeof(double));
+    std::memcpy(&H->lights[(size_t)i * 6 + 3], D.lights[i].origin, 3 * sizeof(double));
+  }
+  H->n_lights = (int32_t)D.n_lights;
+  if (pb.ops.empty()) {  // empty world: one group whose rejected branch ends the program
+    pb.ops.push_back({OP_GROUP, 0, 1, 0});
+    pb.group_box.insert(pb.group_box.end(), {1, 1, 1, 0, 0, 0});
+  }
+  H->ops = std::move(pb.ops);
+  H->group_box = std::move(pb.group_box);
+  H->bvh = std::move(pb.bvh_nodes);
+  H->mtri = std::move(pb.mtri);
+  H->mtri_prim = std::move(pb.mtri_prim);
+  H->item_prim = std::move(pb.item_prim);
+  H->quirk_prim = std::move(pb.quirk_prim);
+  H->bvh_depth = pb.max_depth;
+  return RTC_OK;
+}
+
+}  // namespace rtb

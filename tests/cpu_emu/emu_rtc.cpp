@@ -1,0 +1,91 @@
+// tests/cpu_emu/emu_rtc.cpp — TEST INFRASTRUCTURE.
+// Implements the rtc.h entry points by running the product's kernel source lane-by-lane on the CPU
+// (see shim/hip/hip_runtime.h).  Linked with the product's rtw_capi.cpp into tests/cpu_emu/_build/librtc_emu.so
+// so the same Python harness can drive it.  Used to debug kernel logic and to run sanitizers; it is never
+// loaded by the raytracer_challenge_amd package and proves nothing about the GPU build by itself.
+#include "shim/hip/hip_runtime.h"
+
+#include "../../raytracer_challenge_amd/csrc/rtc_kernels.hip"
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/rtc.h"
+#include "../../raytracer_challenge_amd/csrc/scene_build.hpp"
+
+struct rtc_scene {
+  rtb::HostArrays H;
+  DScene d;
+};
+static thread_local std::string g_err;
+static int efail(int c, const std::string& m) { g_err = m; return c; }
+
+static int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* rgb, rtc_hit* hits, rtc_stats* stats) {
+  if (fuel < 0) fuel = 0;
+  if (fuel > RTC_MAX_FUEL) return efail(RTC_ERR_INVALID, "fuel exceeds RTC_MAX_FUEL");
+  std::vector<double> t(hits ? pm.n : 0);
+  std::vector<int> p(hits ? pm.n : 0), k(hits ? pm.n : 0);
+  DStats st;
+  std::memset(&st, 0, sizeof(st));
+  rtc_launch_trace(s->d, cam, pm, fuel, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr);
+  if (hits) for (uint64_t i = 0; i < pm.n; i++) hits[i] = {t[i], p[i], k[i]};
+  if (stats) {
+    std::memset(stats, 0, sizeof(*stats));
+    stats->pixels = pm.n;
+    stats->rays_primary = st.rays_primary; stats->rays_shadow = st.rays_shadow; stats->rays_reflect = st.rays_reflect; stats->rays_refract = st.rays_refract;
+    stats->rays_container = st.rays_container; stats->accel_nodes = st.accel_nodes; stats->group_tests = st.group_tests; stats->tri_tests = st.tri_tests;
+    stats->analytic_tests = st.analytic_tests; stats->nan_ts = st.nan_ts;
+    stats->n_launches = 1;
+  }
+  if (st.nan_ts) return efail(RTC_ERR_NAN, "NaN intersection t");
+  return RTC_OK;
+}
+static void to_dcam(const rtc_camera& c, DCamera* d) {
+  d->hsize = c.hsize; d->vsize = c.vsize; d->half_width = c.half_width; d->half_height = c.half_height; d->pixel_size = c.pixel_size;
+  std::memcpy(d->inv, c.transform_inv, sizeof(d->inv));
+}
+
+extern "C" {
+const char* rtc_last_error(void) { return g_err.c_str(); }
+int rtc_device_count(void) { return 0; }
+int rtc_scene_create(const rtc_scene_desc* desc, int, rtc_scene** out) {
+  std::unique_ptr<rtc_scene> s(new rtc_scene());
+  std::string err;
+  int rc = rtb::build_arrays(*desc, &s->H, &err);
+  if (rc != RTC_OK) return efail(rc, err);
+  s->d = s->H.view();
+  *out = s.release();
+  return RTC_OK;
+}
+void rtc_scene_destroy(rtc_scene* s) { delete s; }
+uint64_t rtc_scene_device_bytes(const rtc_scene*) { return 0; }
+int rtc_render(rtc_scene* s, const rtc_camera* cam, int32_t fuel, const uint64_t* idx, uint64_t first, uint64_t n, double* rgb, rtc_hit* hits, rtc_stats* stats) {
+  DPixelMap pm{};
+  pm.n = n; pm.first = first; pm.mode = idx ? 1 : 0; pm.indices = idx;
+  DCamera dc;
+  to_dcam(*cam, &dc);
+  return run(s, dc, pm, fuel, rgb, hits, stats);
+}
+int rtc_render_rows_device(rtc_scene* s, const rtc_camera* cam, int32_t fuel, uint32_t row_first, uint32_t row_step, uint32_t n_rows, double* rgb, rtc_stats* stats, int, int) {
+  DPixelMap pm{};
+  pm.n = (uint64_t)n_rows * cam->hsize; pm.mode = 2; pm.row_first = row_first; pm.row_step = row_step;
+  DCamera dc;
+  to_dcam(*cam, &dc);
+  return run(s, dc, pm, fuel, rgb, nullptr, stats);
+}
+int rtc_trace_rays(rtc_scene* s, const double* rays, uint64_t n, int32_t fuel, double* rgb, rtc_hit* hits, rtc_stats* stats) {
+  DPixelMap pm{};
+  pm.n = n; pm.mode = 3; pm.rays = rays;
+  DCamera dc{};
+  dc.hsize = 1; dc.vsize = 1;
+  return run(s, dc, pm, fuel, rgb, hits, stats);
+}
+int rtc_scene_sync(rtc_scene*) { return RTC_OK; }
+void rtc_scene_accel_info(const rtc_scene* s, uint32_t* n_ops, uint32_t* n_bvh_nodes, uint32_t* n_mesh_tris, uint32_t* bvh_depth) {
+  if (n_ops) *n_ops = (uint32_t)s->H.ops.size();
+  if (n_bvh_nodes) *n_bvh_nodes = (uint32_t)s->H.bvh.size();
+  if (n_mesh_tris) *n_mesh_tris = (uint32_t)s->H.mtri_prim.size();
+  if (bvh_depth) *bvh_depth = (uint32_t)s->H.bvh_depth;
+}
+}

@@ -1,0 +1,28 @@
+"""Shared parity checks: a backend under test vs the CPU oracle on the same scene description."""
+import numpy as np
+
+RGB_TOL = 1e-5  # BASELINE.json north_star: "pixels match the reference CPU render within 1e-5 per RGB channel"
+
+
+def assert_parity(test_backend, orc, world, camera, fuel=5, pixel_indices=None, label=""):
+    """Hit records must be bit-exact (t as u64 bits, primitive sequence number, push index); colours within RGB_TOL."""
+    nw_t, nw_o = test_backend.build_world(world), orc.build_world(world)
+    rgb, hits = test_backend.render(nw_t, camera, fuel, pixel_indices)
+    ref_rgb, ref_hits = orc.render(nw_o, camera, fuel, pixel_indices)
+    bad = (hits["prim"] != ref_hits["prim"]) | (hits["push_idx"] != ref_hits["push_idx"]) | (hits["t"].view(np.uint64) != ref_hits["t"].view(np.uint64))
+    assert not bad.any(), "%s: %d/%d primary-hit records differ, first at %s: got %s want %s" % (
+        label, int(bad.sum()), bad.size, np.flatnonzero(bad)[:3], hits[bad][:3], ref_hits[bad][:3])
+    err = float(np.abs(rgb - ref_rgb).max()) if rgb.size else 0.0
+    assert err <= RGB_TOL, "%s: max |dRGB| = %.3e > %.0e" % (label, err, RGB_TOL)
+    return err
+
+
+def assert_ray_parity(test_backend, orc, world, rays, fuel=5, label=""):
+    nw_t, nw_o = test_backend.build_world(world), orc.build_world(world)
+    rgb, hits = test_backend.color_at(nw_t, rays, fuel)
+    ref_rgb, ref_hits = orc.color_at(nw_o, rays, fuel)
+    bad = (hits["prim"] != ref_hits["prim"]) | (hits["push_idx"] != ref_hits["push_idx"]) | (hits["t"].view(np.uint64) != ref_hits["t"].view(np.uint64))
+    assert not bad.any(), "%s: %d/%d hit records differ: got %s want %s" % (label, int(bad.sum()), bad.size, hits[bad][:3], ref_hits[bad][:3])
+    err = float(np.abs(rgb - ref_rgb).max()) if rgb.size else 0.0
+    assert err <= RGB_TOL, "%s: max |dRGB| = %.3e" % (label, err)
+    return err

@@ -1,0 +1,105 @@
+"""CPU tests of the product's host logic and kernel *source* (no GPU):
+  * the kernel source compiled for the CPU (tests/cpu_emu) against the oracle — logic parity, every case of tests/cases.py;
+  * flatten/validation/error behaviour of the host mirror;
+  * librtc_amd.so loads and exports every symbol include/*.h declares; compute entry points fail loudly without a device.
+The GPU parity tests proper are in test_parity_gpu.py (-m gpu)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import raytracer_challenge_amd as rt
+from raytracer_challenge_amd import scenes
+from raytracer_challenge_amd.scene import Color, Element, GroupKind, Material, Matrix, Pattern, PointLight, ShapeArgs, Vector, World, Camera
+import cases
+from parity import assert_parity, assert_ray_parity
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from emu_lib import emu as _emu
+    return _emu()
+
+
+@pytest.mark.parametrize("name", sorted(cases.SMALL_CASES))
+def test_emulated_kernel_matches_oracle(emu, orc, name):
+    cam, world = cases.SMALL_CASES[name]()
+    assert_parity(emu, orc, world, cam, 5, label=name)
+
+
+@pytest.mark.parametrize("fuel", [0, 1, 8])
+def test_emulated_kernel_fuel(emu, orc, fuel):
+    cam, world = cases.nested_glass()
+    assert_parity(emu, orc, world, cam, fuel, label="nested_glass fuel=%d" % fuel)
+
+
+def test_emulated_kernel_edge_rays(emu, orc):
+    for name in ("all_primitives", "nested_glass", "nested_groups"):
+        _, world = cases.SMALL_CASES[name]()
+        assert_ray_parity(emu, orc, world, cases.edge_rays(2048), 5, label=name)
+
+
+def test_emulated_kernel_pixel_subset_and_empty(emu, orc):
+    cam, world = scenes.chapter11_title(64, 36)
+    idx = np.array([0, 5, 63, 64, 1000, 64 * 36 - 1], dtype=np.uint64)
+    assert_parity(emu, orc, world, cam, 5, idx, label="subset")
+    rgb, hits = emu.render(emu.build_world(world), cam, 5, np.zeros(0, dtype=np.uint64))
+    assert rgb.shape == (0, 3) and hits.shape == (0,)
+    empty_world = World([PointLight(Color.white(), Vector.point(0, 5, 0))], [])
+    rgb, hits = emu.render(emu.build_world(empty_world), cam, 5)
+    assert not rgb.any() and (hits["prim"] == -1).all()
+
+
+def declared(header, prefix):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(%s_[a-z_0-9]+)\s*\(" % prefix, text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(os.path.join(ROOT, "raytracer_challenge_amd", "csrc", "librtc_amd.so"))
+    names = declared("rtc.h", "rtc") + declared("rtw.h", "rtw")
+    assert len(names) >= 28, names
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    lib.rtw_backend.restype = C.c_char_p
+    assert lib.rtw_backend() == b"hip"
+
+
+def test_host_errors_and_flatten(emu):
+    b = rt.Backend(os.path.join(ROOT, "raytracer_challenge_amd", "csrc", "librtc_amd.so"))
+    singular = Matrix([[1, 0, 0, 0], [0, 0, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    with pytest.raises(rt.RtwError, match="singular"):
+        b.build_world(World([], [Element.sphere(ShapeArgs(transform=singular))]))       # reference asserts det != 0
+    with pytest.raises(rt.RtwError, match="two children"):
+        b.build_world(World([], [Element.composite(Matrix.id(), None, GroupKind.Union, [Element.sphere()])]))  # src/shape.rs:82
+    with pytest.raises(rt.RtwError, match="cannot open"):
+        b.build_world(World([], [Element.obj("/nonexistent.obj", Matrix.id(), Material())]))
+    # flatten sizes of the teapot scene: 3 planes + 240 triangles, one shared xform for the whole OBJ group
+    cam, world = scenes.chapter15_teapot("teapot_low.obj", 16, 9)
+    nw = b.build_world(world)
+    assert nw.primitive_count == 243
+    counts = (C.c_uint32 * 8)()
+    b.lib.rtw_world_flatten_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    assert b.lib.rtw_world_flatten_counts(nw.handle, counts) == 0
+    n_nodes, n_prims, n_xforms, n_limits, n_tris, n_materials, n_pats, n_lights = list(counts)
+    assert (n_nodes, n_prims, n_xforms, n_tris, n_lights) == (244, 243, 4, 240, 2) and n_materials == 2
+    # CSG is valid in the reference but not on device: scene creation must say so, not render wrongly
+    csg = World([PointLight(Color.white(), Vector.point(0, 5, -5))], [Element.composite(Matrix.id(), None, GroupKind.Difference, [Element.cube(), Element.sphere()])])
+    with pytest.raises(rt.RtwError, match="not supported on device"):
+        emu.render(emu.build_world(csg), cam, 5)
+
+
+def test_no_device_fails_loudly():
+    """Without a GPU the product must refuse to compute (no CPU fallback).  Skipped when a device is present."""
+    b = rt.Backend(os.path.join(ROOT, "raytracer_challenge_amd", "csrc", "librtc_amd.so"))
+    b.lib.rtc_device_count.restype = C.c_int
+    if b.lib.rtc_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    cam, world = scenes.default_world()
+    with pytest.raises(rt.RtwError, match="no HIP device"):
+        b.render(b.build_world(world), cam, 5)
