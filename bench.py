@@ -46,6 +46,19 @@ def make_workload(name):
     return cam, world, desc
 
 
+def cpu_threads():
+    """Threads this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box hands one GPU a
+    16-core share of a 256-thread host)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("RTC_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(world, cam, fuel, target_seconds=15.0):
     """Oracle (CPU restatement) on a bounded, strided pixel sample of the same frame.  Returns the JSON object."""
     import numpy as np
@@ -55,16 +68,17 @@ def cpu_baseline(world, cam, fuel, target_seconds=15.0):
     nw = orc.build_world(world)
     total = cam.hsize * cam.vsize
     probe = np.arange(0, total, max(1, total // 2048), dtype=np.uint64)[:2048]
-    _, _, st = orc.render_timed(nw, cam, fuel, probe, threads=0)
+    threads = cpu_threads()
+    _, _, st = orc.render_timed(nw, cam, fuel, probe, threads=threads)
     per_px = max(st.seconds / len(probe), 1e-9)
     n = int(min(total, max(4096, target_seconds / per_px)))
     stride = max(1, total // n)
     idx = np.arange(0, total, stride, dtype=np.uint64)
-    _, _, st = orc.render_timed(nw, cam, fuel, idx, threads=0)
+    _, _, st = orc.render_timed(nw, cam, fuel, idx, threads=threads)
     return {
         "value": st.unique_rays / st.seconds / 1e6, "unit": "Mrays/s", "cores": int(st.threads), "kind": "port",
         "sample": "every %d-th pixel of the frame (%d px, %.1f s): oracle = C++ restatement of the reference algorithm "
-                  "(flat groups, all-hits + stable sort, per-light re-tracing), std::thread per logical core" % (stride, len(idx), st.seconds),
+                  "(flat groups, all-hits + stable sort, per-light re-tracing), %d std::threads" % (stride, len(idx), st.seconds, threads),
         "reference_traced_mrays_per_s": st.traced_rays / st.seconds / 1e6,
     }
 

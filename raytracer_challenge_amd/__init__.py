@@ -23,6 +23,12 @@ def hip_backend() -> Backend:
     """The one product backend (librtc_amd.so: flatten -> HIP kernels).  No CPU fallback exists."""
     global _backend
     if _backend is None:
+        # PyTorch-ROCm ships its own libamdhip64; whichever copy is loaded first serves the whole process, and torch
+        # cannot see the GPU through the system copy.  Load torch's first so both share one HIP runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _backend = Backend(_LIB)
         if _backend.name != "hip":
             raise RtwError("%s is not the HIP backend (reports %r)" % (_LIB, _backend.name))

@@ -10,12 +10,15 @@
 //   OP_BVH    a = BVH root: world-space BVH over analytic primitives; leaves index item_prim
 //   OP_QUIRK  a = first, b = count in quirk_prim: the cubes and cones of the preceding OP_BVH, scanned linearly for
 //             rays in the state where the reference reports intersections outside the primitive's bounds
+//   OP_QGRID  a = index into qgrids: the same scan, culled by ray DIRECTION: whether a ray is a quirk ray for a cube /
+//             cone depends only on its direction (thin bands on the direction sphere), so a cube-map grid of
+//             directions lists, per cell, the few primitives whose band can touch the cell
 // The accelerator may only skip primitives whose exact test would not produce an intersection with t inside
 // the interval the current pass cares about, so hit records are independent of it.
 #pragma once
 #include <stdint.h>
 
-enum { OP_PRIM = 0, OP_GROUP = 1, OP_MESH = 2, OP_BVH = 3, OP_QUIRK = 4 };
+enum { OP_PRIM = 0, OP_GROUP = 1, OP_MESH = 2, OP_BVH = 3, OP_QUIRK = 4, OP_QGRID = 5 };
 
 struct DOp {
   int32_t op, a, b, c;
@@ -31,6 +34,13 @@ struct DBvhNode {
   int32_t pad[2];
 };
 static_assert(sizeof(DBvhNode) == 64, "BVH node must be one 64-byte line");
+
+// Direction grid of one OP_QGRID: cube map, n x n cells per face; cell c owns qitem[qcell[cell_off + c] .. qcell[cell_off + c + 1]).
+// Rays shorter than RTC_QGRID_MIN_LEN (or non-finite) scan quirk_prim[lin_first .. +lin_count) instead.
+struct DQuirkGrid {
+  int32_t n, cell_off, lin_first, lin_count;
+};
+#define RTC_QGRID_MIN_LEN 0.05
 
 struct DPrim {  // 32 bytes
   int32_t geom;
@@ -59,6 +69,9 @@ struct DScene {
   const int32_t* mtri_prim;  // -> primitive sequence number
   const int32_t* item_prim;  // OP_BVH leaf items -> primitive index
   const int32_t* quirk_prim; // OP_QUIRK items -> primitive index (cubes, cones)
+  const DQuirkGrid* qgrids;
+  const uint32_t* qcell;     // per-cell offsets into qitem
+  const int32_t* qitem;      // primitive indices
   const DPrim* prims;
   const double* xf_inv;      // n_xforms x 12 (rows 0..2 of Shape.transform_inv)
   const double* xf_matinv;   // n_xforms x 16 (Shape.material_inv)

@@ -252,6 +252,27 @@ __device__ __forceinline__ void visit_prim(const DScene& S, int prim, const Ray&
   accept(S, T, C, prim, n, t, u, v);
 }
 
+// Direction-grid culled quirk scan (device_scene.h OP_QGRID).  The cell lookup must mirror build_quirk_grid().
+__device__ __forceinline__ void quirk_grid_scan(const DScene& S, const DQuirkGrid G, const Ray& r, Trav& T, Counters& C) {
+  double ax = fabs(r.dx), ay = fabs(r.dy), az = fabs(r.dz);
+  double len2 = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
+  if (!(len2 >= RTC_QGRID_MIN_LEN * RTC_QGRID_MIN_LEN) || !(len2 < DINF)) {
+    for (int i = G.lin_first; i < G.lin_first + G.lin_count; i++) visit_prim(S, S.quirk_prim[i], r, T, C, 2);
+    return;
+  }
+  int face;
+  double u, v;
+  if (ax >= ay && ax >= az) { face = r.dx > 0.0 ? 0 : 1; u = r.dy / ax; v = r.dz / ax; }
+  else if (ay >= az) { face = r.dy > 0.0 ? 2 : 3; u = r.dx / ay; v = r.dz / ay; }
+  else { face = r.dz > 0.0 ? 4 : 5; u = r.dx / az; v = r.dy / az; }
+  int iu = (int)((u + 1.0) * 0.5 * (double)G.n), iv = (int)((v + 1.0) * 0.5 * (double)G.n);
+  iu = iu < 0 ? 0 : (iu >= G.n ? G.n - 1 : iu);
+  iv = iv < 0 ? 0 : (iv >= G.n ? G.n - 1 : iv);
+  int cell = G.cell_off + (face * G.n + iv) * G.n + iu;
+  unsigned b = S.qcell[cell], e = S.qcell[cell + 1];
+  for (unsigned i = b; i < e; i++) visit_prim(S, S.qitem[i], r, T, C, 2);
+}
+
 // ---- accelerator -------------------------------------------------------------------------------------
 // Slab test against an f32 box widened at build time; evaluated in f64, NaN-ignoring min/max, so a box is
 // only rejected when the ray's line misses it or its [tn, tf] misses [tlo, thi].  Returns entry distance.
@@ -321,6 +342,9 @@ __device__ __forceinline__ void traverse(const DScene& S, const Ray& r, Trav& T,
       pc++;
     } else if (op.op == OP_QUIRK) {
       for (int i = op.a; i < op.a + op.b; i++) visit_prim(S, S.quirk_prim[i], r, T, C, 2);
+      pc++;
+    } else if (op.op == OP_QGRID) {
+      quirk_grid_scan(S, S.qgrids[op.a], r, T, C);
       pc++;
     } else if (op.op == OP_GROUP) {
       C.group_tests++;

@@ -148,7 +148,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     int rc_ = s->upload(H.field, &d.field);                             \
     if (rc_ != RTC_OK) { rtc_scene_destroy(s.release()); return rc_; } \
   } while (0)
-  UP(ops); UP(group_box); UP(bvh); UP(mtri); UP(mtri_prim); UP(item_prim); UP(quirk_prim); UP(prims); UP(xf_inv); UP(xf_matinv); UP(limits);
+  UP(ops); UP(group_box); UP(bvh); UP(mtri); UP(mtri_prim); UP(item_prim); UP(quirk_prim); UP(qgrids); UP(qcell); UP(qitem); UP(prims); UP(xf_inv); UP(xf_matinv); UP(limits);
   UP(tri_geo); UP(tri_nrm); UP(mat); UP(mat_pattern); UP(pats); UP(lights);
 #undef UP
   d.n_ops = (int32_t)H.ops.size();

@@ -23,7 +23,9 @@ struct ProgramBuilder {
   std::vector<double> group_box;
   std::vector<DBvhNode> bvh_nodes;
   std::vector<double> mtri;
-  std::vector<int32_t> mtri_prim, item_prim, quirk_prim;
+  std::vector<int32_t> mtri_prim, item_prim, quirk_prim, qitem;
+  std::vector<DQuirkGrid> qgrids;
+  std::vector<uint32_t> qcell;
   int max_depth = 0;
   std::string error;
   int status = RTC_OK;
@@ -82,6 +84,79 @@ struct ProgramBuilder {
       out->hi[a] += pad;
     }
     return true;
+  }
+
+  static constexpr int32_t kMinQuirkGrid = 8;
+
+  // Direction grid for quirk_prim[q0, q0+qn).  A ray is a quirk ray for
+  //   a cube iff |row_i(M) . d| < EPSILON for some object axis i          (src/shape.rs:641),
+  //   a cone iff |(r0.d)^2 - (r1.d)^2 + (r2.d)^2| < EPSILON               (src/shape.rs:784),
+  // with M = transform_inv's 3x3 part: conditions on the direction only.  For a unit direction u in a cell with centre c
+  // and chord radius rho, |r.u| >= |r.c| - |r| rho, so the primitive is listed in the cell iff the bound cannot exclude
+  // it for any ray of length >= RTC_QGRID_MIN_LEN; shorter rays take the linear scan.
+  int32_t build_quirk_grid(int32_t q0, int32_t qn) {
+    int bands = 0;
+    for (int32_t i = 0; i < qn; i++) bands += D.prims[quirk_prim[q0 + i]].geometry == RTC_CUBE ? 3 : 1;
+    int n = std::min(256, std::max(8, (int)std::ceil(0.14 * bands)));
+    DQuirkGrid g{n, (int32_t)qcell.size(), q0, qn};
+    const double eps = 0.00001, lmin = RTC_QGRID_MIN_LEN;
+    struct Rows { double r[3][3], len[3]; bool cube; int32_t prim; };
+    std::vector<Rows> rows(qn);
+    for (int32_t i = 0; i < qn; i++) {
+      const rtc_prim& p = D.prims[quirk_prim[q0 + i]];
+      const double* m = D.xforms[p.xform].transform_inv;
+      Rows& R = rows[i];
+      R.cube = p.geometry == RTC_CUBE;
+      R.prim = quirk_prim[q0 + i];
+      for (int a = 0; a < 3; a++) {
+        for (int c = 0; c < 3; c++) R.r[a][c] = m[4 * a + c];
+        R.len[a] = std::sqrt(R.r[a][0] * R.r[a][0] + R.r[a][1] * R.r[a][1] + R.r[a][2] * R.r[a][2]);
+      }
+    }
+    auto dir = [](int face, double u, double v, double* out) {
+      double s = (face & 1) ? -1.0 : 1.0;
+      switch (face >> 1) {
+        case 0: out[0] = s; out[1] = u; out[2] = v; break;
+        case 1: out[0] = u; out[1] = s; out[2] = v; break;
+        default: out[0] = u; out[1] = v; out[2] = s; break;
+      }
+      double l = std::sqrt(out[0] * out[0] + out[1] * out[1] + out[2] * out[2]);
+      out[0] /= l; out[1] /= l; out[2] /= l;
+    };
+    for (int face = 0; face < 6; face++)
+      for (int iv = 0; iv < n; iv++)
+        for (int iu = 0; iu < n; iu++) {
+          qcell.push_back((uint32_t)qitem.size());
+          double c[3], rho = 0.0;
+          dir(face, (iu + 0.5) / n * 2.0 - 1.0, (iv + 0.5) / n * 2.0 - 1.0, c);
+          for (int k = 0; k < 4; k++) {
+            double q[3];
+            dir(face, (iu + (k & 1)) / (double)n * 2.0 - 1.0, (iv + (k >> 1)) / (double)n * 2.0 - 1.0, q);
+            double dx = q[0] - c[0], dy = q[1] - c[1], dz = q[2] - c[2];
+            rho = std::max(rho, std::sqrt(dx * dx + dy * dy + dz * dz));
+          }
+          rho = rho * (1.0 + 1e-6) + 1e-9;  // device and host may disagree on the cell of a direction on an edge
+          for (const Rows& R : rows) {
+            bool in = false;
+            if (R.cube) {
+              for (int a = 0; a < 3 && !in; a++) {
+                double f = std::fabs(R.r[a][0] * c[0] + R.r[a][1] * c[1] + R.r[a][2] * c[2]);
+                in = !(f > eps / lmin + R.len[a] * rho);
+              }
+            } else {
+              double e0 = R.r[0][0] * c[0] + R.r[0][1] * c[1] + R.r[0][2] * c[2];
+              double e1 = R.r[1][0] * c[0] + R.r[1][1] * c[1] + R.r[1][2] * c[2];
+              double e2 = R.r[2][0] * c[0] + R.r[2][1] * c[1] + R.r[2][2] * c[2];
+              double gq = std::fabs(e0 * e0 - e1 * e1 + e2 * e2);
+              double lip = 2.0 * rho * (R.len[0] * R.len[0] + R.len[1] * R.len[1] + R.len[2] * R.len[2]);
+              in = !(gq > eps / (lmin * lmin) + lip);
+            }
+            if (in) qitem.push_back(R.prim);
+          }
+        }
+    qcell.push_back((uint32_t)qitem.size());
+    qgrids.push_back(g);
+    return (int32_t)qgrids.size() - 1;
   }
 
   int32_t build_tree(const std::vector<bvh::Item>& items, std::vector<uint32_t>& order, uint32_t base) {
@@ -153,7 +228,9 @@ struct ProgramBuilder {
         int32_t q0 = (int32_t)quirk_prim.size();
         for (int32_t pi : ids)
           if (D.prims[pi].geometry == RTC_CUBE || D.prims[pi].geometry == RTC_CONE) quirk_prim.push_back(pi);
-        if ((int32_t)quirk_prim.size() > q0) ops.push_back({OP_QUIRK, q0, (int32_t)quirk_prim.size() - q0, 0});
+        int32_t qn = (int32_t)quirk_prim.size() - q0;
+        if (qn >= kMinQuirkGrid) ops.push_back({OP_QGRID, build_quirk_grid(q0, qn), 0, 0});
+        else if (qn > 0) ops.push_back({OP_QUIRK, q0, qn, 0});
       }
     }
     // 3. child groups: exact reference box test, then their own program
@@ -232,7 +309,9 @@ struct HostArrays {
   std::vector<double> group_box;
   std::vector<DBvhNode> bvh;
   std::vector<double> mtri;
-  std::vector<int32_t> mtri_prim, item_prim, quirk_prim;
+  std::vector<int32_t> mtri_prim, item_prim, quirk_prim, qitem;
+  std::vector<DQuirkGrid> qgrids;
+  std::vector<uint32_t> qcell;
   std::vector<DPrim> prims;
   std::vector<double> xf_inv, xf_matinv, limits, tri_geo, tri_nrm, mat;
   std::vector<int32_t> mat_pattern;
@@ -243,7 +322,7 @@ struct HostArrays {
   DScene view() const {
     DScene d{};
     d.ops = ops.data(); d.group_box = group_box.data(); d.bvh = bvh.data(); d.mtri = mtri.data(); d.mtri_prim = mtri_prim.data();
-    d.item_prim = item_prim.data(); d.quirk_prim = quirk_prim.data(); d.prims = prims.data(); d.xf_inv = xf_inv.data(); d.xf_matinv = xf_matinv.data(); d.limits = limits.data();
+    d.item_prim = item_prim.data(); d.quirk_prim = quirk_prim.data(); d.qgrids = qgrids.data(); d.qcell = qcell.data(); d.qitem = qitem.data(); d.prims = prims.data(); d.xf_inv = xf_inv.data(); d.xf_matinv = xf_matinv.data(); d.limits = limits.data();
     d.tri_geo = tri_geo.data(); d.tri_nrm = tri_nrm.data(); d.mat = mat.data(); d.mat_pattern = mat_pattern.data(); d.pats = pats.data();
     d.lights = lights.data();
     d.n_ops = (int32_t)ops.size(); d.n_prims = (int32_t)prims.size(); d.n_lights = n_lights; d.all_cast_shadow = all_cast_shadow;
@@ -307,6 +386,9 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
   H->mtri_prim = std::move(pb.mtri_prim);
   H->item_prim = std::move(pb.item_prim);
   H->quirk_prim = std::move(pb.quirk_prim);
+  H->qgrids = std::move(pb.qgrids);
+  H->qcell = std::move(pb.qcell);
+  H->qitem = std::move(pb.qitem);
   H->bvh_depth = pb.max_depth;
   return RTC_OK;
 }

@@ -88,6 +88,22 @@ def nested_groups():
     return _cam(64, 40, 0.9, (3, 3, -6), (0.5, 0, 0)), World([PointLight(Color.white(), Vector.point(-4, 8, -6))], [ring, blob, floor_in_group, empty])
 
 
+def cube_lattice():
+    """4x4x4 axis-aligned cubes + a few cones: axis-parallel rays are 'quirk rays' (|d|<EPSILON slab rule, src/shape.rs:641)
+    for every cube at once, which stresses the direction-grid culled scan (OP_QGRID)."""
+    els = [Element.plane(ShapeArgs(transform=Matrix.translation(0, -4, 0)))]
+    for i in range(4):
+        for j in range(4):
+            for k in range(4):
+                t = Matrix.translation(2.0 * i - 3.0, 2.0 * j - 3.0, 2.0 * k - 3.0) * Matrix.scaling(0.6, 0.6, 0.6)
+                mat = Material(pattern=Pattern.plain(Color.new(0.2 + 0.2 * i, 0.2 + 0.2 * j, 0.2 + 0.2 * k)), reflective=0.3 if (i + j + k) % 3 == 0 else 0.0,
+                               transparency=0.8 if (i + j + k) % 5 == 0 else 0.0, refractive_index=1.3)
+                els.append(Element.cube(ShapeArgs(transform=t, material=mat)))
+    for i in range(4):
+        els.append(Element.cone(ShapeArgs(transform=Matrix.translation(2.0 * i - 3.0, 4.5, 0.0) * Matrix.rotation_z(0.2 * i)), -1.0, 0.0, True))
+    return _cam(64, 48, 1.0, (0.0, 0.0, -14.0), (0, 0, 0)), World([PointLight(Color.white(), Vector.point(-8, 12, -12))], els)
+
+
 def edge_rays(n=4096, seed=7):
     """Rays for color_at parity: random, axis-parallel (the |d|<EPSILON slab rule), grazing, starting inside shapes, zero-ish components."""
     rng = np.random.default_rng(seed)
@@ -117,4 +133,5 @@ SMALL_CASES = {
     "all_primitives": all_primitives,
     "patterns_and_noise": patterns_and_noise,
     "nested_groups": nested_groups,
+    "cube_lattice": cube_lattice,
 }

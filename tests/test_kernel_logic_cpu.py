@@ -38,7 +38,7 @@ def test_emulated_kernel_fuel(emu, orc, fuel):
 
 
 def test_emulated_kernel_edge_rays(emu, orc):
-    for name in ("all_primitives", "nested_glass", "nested_groups"):
+    for name in ("all_primitives", "nested_glass", "nested_groups", "cube_lattice", "synthetic_cones_grouped"):
         _, world = cases.SMALL_CASES[name]()
         assert_ray_parity(emu, orc, world, cases.edge_rays(2048), 5, label=name)
 

@@ -30,7 +30,7 @@ def test_hip_fuel(hip, orc, fuel):
 
 
 def test_hip_edge_rays(hip, orc):
-    for name in ("all_primitives", "nested_glass", "nested_groups", "synthetic_cones_grouped"):
+    for name in ("all_primitives", "nested_glass", "nested_groups", "synthetic_cones_grouped", "cube_lattice"):
         _, world = cases.SMALL_CASES[name]()
         assert_ray_parity(hip, orc, world, cases.edge_rays(4096), 5, label=name)
 
