@@ -9,6 +9,13 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+def pytest_sessionstart(session):
+    """Keep every native piece in step with its sources (no-ops when up to date; hipcc cross-compiles without a GPU)."""
+    import subprocess
+    for d in ("raytracer_challenge_amd/csrc", "oracle", "tests/cpu_emu"):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, d)], check=True)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
