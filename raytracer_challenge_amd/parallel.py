@@ -1,0 +1,50 @@
+"""Tile partition of one frame over the GPUs of a node and the end-of-frame gather.
+
+Pixels are independent (reference src/image.rs:68-73), so the only exchange is one gather of finished tiles to rank 0.
+Rows are dealt round-robin — rank r of N owns rows r, r+N, r+2N, … — because contiguous blocks are badly imbalanced
+(the mesh and its reflections sit mid-frame).  `torch.distributed` is plumbing: backend "nccl" is RCCL over xGMI on the
+GPUs, "gloo" in the CPU tests.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+
+def rows_of(rank: int, world_size: int, vsize: int) -> range:
+    """Image rows owned by `rank`."""
+    return range(rank, vsize, world_size)
+
+
+def max_rows(world_size: int, vsize: int) -> int:
+    return len(rows_of(0, world_size, vsize))
+
+
+class FrameGatherer:
+    """Owns the gather buffers of one frame size.  `tile` is each rank's dense buffer of its own rows (float64,
+    max_rows*hsize*3, padded when vsize % world_size != 0)."""
+
+    def __init__(self, hsize: int, vsize: int, rank: int, world_size: int, device, dist=None):
+        import torch
+        self.hsize, self.vsize, self.rank, self.world_size, self.dist = hsize, vsize, rank, world_size, dist
+        self.n_rows = len(rows_of(rank, world_size, vsize))
+        self.tile = torch.zeros(max_rows(world_size, vsize) * hsize * 3, dtype=torch.float64, device=device)
+        self.gathered: Optional[List] = None
+        self.image = None
+        if rank == 0:
+            self.image = torch.zeros((vsize, hsize, 3), dtype=torch.float64, device=device)
+            if world_size > 1:
+                self.gathered = [torch.zeros_like(self.tile) for _ in range(world_size)]
+
+    def gather(self):
+        """All ranks call this after filling `tile`.  Rank 0 returns the assembled (vsize, hsize, 3) image, others None."""
+        H, V, N = self.hsize, self.vsize, self.world_size
+        if N == 1:
+            self.image.view(-1)[:] = self.tile[: V * H * 3]
+            return self.image
+        self.dist.gather(self.tile, self.gathered, dst=0)
+        if self.rank != 0:
+            return None
+        for r in range(N):
+            nr = len(rows_of(r, N, V))
+            self.image[r::N] = self.gathered[r][: nr * H * 3].view(nr, H, 3)
+        return self.image
