@@ -15,7 +15,8 @@ from .backend import Backend, RtwError, HIT_DTYPE  # noqa: F401
 
 import os as _os
 
-_LIB = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "csrc", "librtc_amd.so")
+# RTC_AMD_LIB lets a tuning run point at another build of the same HIP library (csrc/variants/); never a CPU library.
+_LIB = _os.environ.get("RTC_AMD_LIB") or _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "csrc", "librtc_amd.so")
 _backend = None
 
 

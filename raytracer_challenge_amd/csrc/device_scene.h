@@ -108,4 +108,6 @@ struct DStats {  // device-side counters (atomically accumulated per wave)
 };
 
 #define RTC_MAX_FUEL 16
+#ifndef RTC_BVH_STACK
 #define RTC_BVH_STACK 48
+#endif

@@ -19,6 +19,20 @@
 #include "device_scene.h"
 
 #define EPS 0.00001
+#ifndef RTC_BLOCK
+#define RTC_BLOCK 64
+#endif
+#ifndef RTC_WAVES_PER_SIMD
+#define RTC_WAVES_PER_SIMD 1
+#endif
+#ifndef RTC_V2_WAVES_PER_SIMD
+#define RTC_V2_WAVES_PER_SIMD 1
+#endif
+#ifdef RTC_TRAVERSE_NOINLINE
+#define TRAVERSE_INLINE __noinline__
+#else
+#define TRAVERSE_INLINE __forceinline__
+#endif
 #define DINF (__builtin_inf())
 
 namespace {
@@ -27,20 +41,18 @@ struct Ray { double ox, oy, oz, dx, dy, dz; };
 
 enum { MODE_CLOSEST = 0, MODE_SHADOW_ANY = 1, MODE_SHADOW_CLOSEST = 2, MODE_CONTAINERS = 3 };
 
-// Per-ray traversal state (registers).
+// Per-ray traversal state (registers).  One layout serves all four passes:
+//   CLOSEST / SHADOW_CLOSEST: best_* = running minimum of (t, prim, push) over t >= 0; thi follows best_t.
+//   SHADOW_ANY: thi = distance to the light; `shadowed` set by any intersection with 0 <= t < thi.
+//   CONTAINERS: (thi, best_prim, best_klast) = key of the hit (left over from the closest pass);
+//               c1/c2 = odd-count shape with the largest (t, prim) before / up to that key (-1 = none).
 struct Trav {
   int mode;
-  double tlo, thi;  // interval of t the pass cares about (accelerator culling only)
-  // nearest hit (CLOSEST / SHADOW_CLOSEST)
-  double best_t, best_u, best_v;
+  double tlo, thi;  // interval of t the pass cares about (also the accelerator's culling interval)
+  double best_t;
   int best_prim, best_k, best_klast;
-  // SHADOW_ANY
-  double dist;
   int shadowed;
-  // CONTAINERS: the hit key, and the two running "last container" candidates
-  double h_t;
-  int h_prim, h_klast;
-  double c1_t, c1_ri, c2_t, c2_ri;
+  double c1_t, c2_t;
   int c1_prim, c2_prim;
 };
 
@@ -94,7 +106,7 @@ __device__ __forceinline__ bool key_before(double t, int prim, int k, double ht,
   return (t < ht) || (t == ht && (prim < hprim || (prim == hprim && k < hk)));
 }
 
-__device__ __forceinline__ void accept(const DScene& S, Trav& T, Counters& C, int prim, int n, const double* t, double u, double v) {
+__device__ __forceinline__ void accept(Trav& T, Counters& C, int prim, int n, const double* t) {
   if (n == 0) return;
   if (T.mode == MODE_CLOSEST || T.mode == MODE_SHADOW_CLOSEST) {
     for (int k = 0; k < n; k++) {
@@ -102,7 +114,7 @@ __device__ __forceinline__ void accept(const DScene& S, Trav& T, Counters& C, in
       if (tk != tk) C.nan_ts++;
       if (tk >= 0.0) {
         if (tk < T.best_t || (tk == T.best_t && prim < T.best_prim)) {
-          T.best_t = tk; T.best_prim = prim; T.best_k = k; T.best_klast = k; T.best_u = u; T.best_v = v;
+          T.best_t = tk; T.best_prim = prim; T.best_k = k; T.best_klast = k;
           T.thi = tk;
         } else if (tk == T.best_t && prim == T.best_prim) {
           T.best_klast = k;
@@ -113,25 +125,21 @@ __device__ __forceinline__ void accept(const DScene& S, Trav& T, Counters& C, in
     for (int k = 0; k < n; k++) {
       double tk = t[k];
       if (tk != tk) C.nan_ts++;
-      if (tk >= 0.0 && tk < T.dist) T.shadowed = 1;
+      if (tk >= 0.0 && tk < T.thi) T.shadowed = 1;
     }
   } else {  // MODE_CONTAINERS
     int cnt1 = 0, cnt2 = 0;
     double m1 = 0.0, m2 = 0.0;
     for (int k = 0; k < n; k++) {
       double tk = t[k];
-      bool b1 = key_before(tk, prim, k, T.h_t, T.h_prim, T.h_klast);
-      bool b2 = b1 || (tk == T.h_t && prim == T.h_prim && k == T.h_klast);
-      // pushes of one primitive are visited in push order, so "largest key so far" = latest k among the largest t
+      bool b1 = key_before(tk, prim, k, T.thi, T.best_prim, T.best_klast);
+      bool b2 = b1 || (tk == T.thi && prim == T.best_prim && k == T.best_klast);
+      // pushes of one primitive arrive in push order, so ">=" keeps the latest push among equal t
       if (b1) { if (cnt1 == 0 || tk >= m1) m1 = tk; cnt1++; }
       if (b2) { if (cnt2 == 0 || tk >= m2) m2 = tk; cnt2++; }
     }
-    if ((cnt1 & 1) && (T.c1_prim < 0 || m1 > T.c1_t || (m1 == T.c1_t && prim > T.c1_prim))) {
-      T.c1_t = m1; T.c1_prim = prim; T.c1_ri = S.mat[8 * S.prims[prim].mat + 6];
-    }
-    if ((cnt2 & 1) && (T.c2_prim < 0 || m2 > T.c2_t || (m2 == T.c2_t && prim > T.c2_prim))) {
-      T.c2_t = m2; T.c2_prim = prim; T.c2_ri = S.mat[8 * S.prims[prim].mat + 6];
-    }
+    if ((cnt1 & 1) && (T.c1_prim < 0 || m1 > T.c1_t || (m1 == T.c1_t && prim > T.c1_prim))) { T.c1_t = m1; T.c1_prim = prim; }
+    if ((cnt2 & 1) && (T.c2_prim < 0 || m2 > T.c2_t || (m2 == T.c2_t && prim > T.c2_prim))) { T.c2_t = m2; T.c2_prim = prim; }
   }
 }
 
@@ -249,7 +257,7 @@ __device__ __forceinline__ void visit_prim(const DScene& S, int prim, const Ray&
   double t[4], u = 0.0, v = 0.0;
   if (P.geom >= 5) C.tri_tests++; else C.analytic_tests++;
   int n = prim_hits(S, P, o, t, u, v);
-  accept(S, T, C, prim, n, t, u, v);
+  accept(T, C, prim, n, t);
 }
 
 // Direction-grid culled quirk scan (device_scene.h OP_QGRID).  The cell lookup must mirror build_quirk_grid().
@@ -318,7 +326,7 @@ __device__ __forceinline__ void bvh_walk(const DScene& S, int root, const Ray& w
         if (MESH) {
           double t, u, v;
           C.tri_tests++;
-          if (tri_hit(S.mtri + 9 * (size_t)i, o, t, u, v)) accept(S, T, C, S.mtri_prim[i], 1, &t, u, v);
+          if (tri_hit(S.mtri + 9 * (size_t)i, o, t, u, v)) accept(T, C, S.mtri_prim[i], 1, &t);
         } else {
           visit_prim(S, S.item_prim[i], world, T, C, 1);
         }
@@ -332,7 +340,7 @@ __device__ __forceinline__ void bvh_walk(const DScene& S, int root, const Ray& w
 }
 
 // World::intersect (src/world.rs:18-24) + Group::intersect (src/shape.rs:248-269) over the flattened program.
-__device__ __forceinline__ void traverse(const DScene& S, const Ray& r, Trav& T, Counters& C, int* __restrict__ stack, int stride) {
+__device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T, Counters& C, int* __restrict__ stack, int stride) {
   int pc = 0;
   const int n = S.n_ops;
   while (pc < n) {
@@ -643,8 +651,19 @@ __device__ __forceinline__ double schlick(const State& st, double n1, double n2)
 __device__ __forceinline__ void reset_closest(Trav& T, int mode) {
   T.mode = mode;
   T.tlo = 0.0; T.thi = DINF;
-  T.best_t = DINF; T.best_prim = 0x7fffffff; T.best_k = 0; T.best_klast = 0; T.best_u = 0.0; T.best_v = 0.0;
-  T.shadowed = 0; T.dist = 0.0;
+  T.best_t = DINF; T.best_prim = 0x7fffffff; T.best_k = 0; T.best_klast = 0;
+  T.shadowed = 0;
+  T.c1_t = 0.0; T.c2_t = 0.0; T.c1_prim = -1; T.c2_prim = -1;
+}
+
+// u, v of the winning triangle: the traversal does not carry them; the same test on the same numbers gives the same bits.
+__device__ __forceinline__ void hit_uv(const DScene& S, const DPrim& P, const Ray& world, double& u, double& v) {
+  u = 0.0; v = 0.0;
+  if (P.geom >= 5) {
+    Ray o = to_object(S.xf_inv + 12 * P.xform, world);
+    double t;
+    tri_hit(S.tri_geo + 9 * P.data, o, t, u, v);
+  }
 }
 
 struct Pending {
@@ -675,12 +694,12 @@ __device__ __forceinline__ Ray camera_ray(const DCamera& cam, uint64_t i) {
 
 // One lane = one pixel.  COUNT selects the variant that publishes work counters.
 template <bool COUNT>
-__global__ void __launch_bounds__(256) rtc_trace_kernel(DScene S, DCamera cam, DPixelMap pm, int fuel0, double* __restrict__ rgb, double* __restrict__ hit_t,
+__global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD) rtc_trace_kernel(DScene S, DCamera cam, DPixelMap pm, int fuel0, double* __restrict__ rgb, double* __restrict__ hit_t,
                                                         int* __restrict__ hit_prim, int* __restrict__ hit_k, DStats* __restrict__ stats) {
-  __shared__ int lds_stack[RTC_BVH_STACK * 256];
+  __shared__ int lds_stack[RTC_BVH_STACK * RTC_BLOCK];
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int* stack = lds_stack + threadIdx.x;
-  const int stride = 256;
+  const int stride = RTC_BLOCK;
   Counters C = {0, 0, 0, 0, 0};
   unsigned n_primary = 0, n_shadow = 0, n_reflect = 0, n_refract = 0, n_container = 0;
 
@@ -725,21 +744,21 @@ __global__ void __launch_bounds__(256) rtc_trace_kernel(DScene S, DCamera cam, D
         const double* M = S.mat + 8 * P.mat;
         const double ambient = M[0], diffuse = M[1], specular = M[2], shininess = M[3], reflective = M[4], transparency = M[5];
         State st;
-        prepare_state(S, P, ray, T.best_t, T.best_u, T.best_v, st);
+        double hu, hv;
+        hit_uv(S, P, ray, hu, hv);
+        prepare_state(S, P, ray, T.best_t, hu, hv, st);
 
         // n1 / n2 / reflectance are only consumed when the surface is transparent (src/world.rs:70-78, :110)
         double n1 = 1.0, n2 = 1.0;
         if (transparency != 0.0) {
           n_container++;
-          Trav K;
+          Trav K = T;  // keeps the hit key (thi = best_t, best_prim, best_klast)
           K.mode = MODE_CONTAINERS;
           K.tlo = -DINF; K.thi = T.best_t;
-          K.h_t = T.best_t; K.h_prim = T.best_prim; K.h_klast = T.best_klast;
-          K.c1_prim = -1; K.c2_prim = -1; K.c1_t = 0.0; K.c2_t = 0.0; K.c1_ri = 1.0; K.c2_ri = 1.0;
-          K.shadowed = 0;
+          K.c1_prim = -1; K.c2_prim = -1; K.c1_t = 0.0; K.c2_t = 0.0;
           traverse(S, ray, K, C, stack, stride);
-          if (K.c1_prim >= 0) n1 = K.c1_ri;
-          if (K.c2_prim >= 0) n2 = K.c2_ri;
+          if (K.c1_prim >= 0) n1 = S.mat[8 * S.prims[K.c1_prim].mat + 6];
+          if (K.c2_prim >= 0) n2 = S.mat[8 * S.prims[K.c2_prim].mat + 6];
         }
 
         // Pattern::color_at(material_inv * over_point) — identical for every light (src/shape.rs:437)
@@ -767,7 +786,6 @@ __global__ void __launch_bounds__(256) rtc_trace_kernel(DScene S, DCamera cam, D
           n_shadow++;
           Trav Sh;
           reset_closest(Sh, S.all_cast_shadow ? MODE_SHADOW_ANY : MODE_SHADOW_CLOSEST);
-          Sh.dist = distance;
           if (S.all_cast_shadow) Sh.thi = distance;
           traverse(S, sray, Sh, C, stack, stride);
           bool shadowed;
@@ -856,12 +874,436 @@ __global__ void __launch_bounds__(256) rtc_trace_kernel(DScene S, DCamera cam, D
   }
 }
 
+// =================================================================================================================
+// v2: persistent waves, ONE traversal loop for every ray kind, memory-resident lane contexts, ballot refill.
+//
+// Each lane owns one pixel at a time and walks its ray tree depth-first, but the wave never runs "a primary-ray
+// loop, then a shadow loop": every lane that has a ray in flight (closest / shadow / container pass alike) takes
+// steps of the same resumable traversal state machine, so lanes in different phases of different pixels share the
+// BVH code.  Everything a lane does not need while traversing (hit state, pattern colour, accumulators, pending
+// child rays) lives in a per-lane context in HBM, SoA by lane so the wave's accesses coalesce.  When enough lanes
+// have finished their traversal the wave leaves the loop, runs their continuations (shade / next light / spawn /
+// next pixel via one wave-aggregated atomic) and re-enters.  The exit condition is reached by every wave: a lane
+// becomes EXIT when the pixel counter is exhausted, and the loop ends when all 64 lanes are EXIT.
+// =================================================================================================================
+#ifndef RTC_WAVE
+#define RTC_WAVE 64
+#endif
+#ifndef RTC_V2_WAIT_LANES
+#define RTC_V2_WAIT_LANES 24  // leave the traversal loop once this many lanes wait for their continuation
+#endif
+
+namespace {
+
+enum { PH_IDLE = 0, PH_TRAV = 1, PH_DONE = 2, PH_EXIT = 3 };
+enum { ST_CLOSEST = 0, ST_CONT = 1, ST_SHADOW = 2 };
+#define CUR_NONE ((int)0x80000000)
+
+// context fields (doubles), index f * nl + lane
+enum { CF_HRAY = 0, CF_TRAY = 6, CF_POINT = 12, CF_NORMAL = 15, CF_COLOR = 18, CF_N1 = 21, CF_N2 = 22, CF_ACC = 23, CF_WEIGHT = 26, CF_T = 27, CF_PEND = 28 };
+// context fields (ints)
+enum { CI_PRIM = 0, CI_PEND = 1 };
+
+struct Lane {  // register-resident state of one lane
+  Ray r;              // ray in the space of the structure being walked (world, or object space inside OP_MESH)
+  double ix, iy, iz;  // 1/direction while inside a BVH
+  Trav T;
+  int pc, cur, sp;    // program counter, BVH cursor (CUR_NONE = at op level), stack depth
+  int in_mesh;        // r is an object-space ray
+  int phase, stage, light, fuel, np, kind;
+  unsigned q;         // output slot of the pixel in flight
+};
+
+__device__ __forceinline__ void ctx_store_ray(double* __restrict__ cd, size_t nl, size_t lane, int f, const Ray& r) {
+  cd[(f + 0) * nl + lane] = r.ox; cd[(f + 1) * nl + lane] = r.oy; cd[(f + 2) * nl + lane] = r.oz;
+  cd[(f + 3) * nl + lane] = r.dx; cd[(f + 4) * nl + lane] = r.dy; cd[(f + 5) * nl + lane] = r.dz;
+}
+__device__ __forceinline__ Ray ctx_load_ray(const double* __restrict__ cd, size_t nl, size_t lane, int f) {
+  Ray r;
+  r.ox = cd[(f + 0) * nl + lane]; r.oy = cd[(f + 1) * nl + lane]; r.oz = cd[(f + 2) * nl + lane];
+  r.dx = cd[(f + 3) * nl + lane]; r.dy = cd[(f + 4) * nl + lane]; r.dz = cd[(f + 5) * nl + lane];
+  return r;
+}
+
+// Leave the BVH the lane is in: next op; back to the world-space ray if it was inside a mesh.
+__device__ __forceinline__ void bvh_exit(Lane& L, const double* __restrict__ cd, size_t nl, size_t lane) {
+  L.cur = CUR_NONE;
+  L.pc++;
+  if (L.in_mesh) { L.r = ctx_load_ray(cd, nl, lane, CF_TRAY); L.in_mesh = 0; }
+}
+__device__ __forceinline__ void bvh_pop(Lane& L, const int* __restrict__ stack, int stride, const double* __restrict__ cd, size_t nl, size_t lane) {
+  if (L.sp == 0) { bvh_exit(L, cd, nl, lane); return; }
+  L.sp--;
+  L.cur = stack[L.sp * stride];
+}
+
+// One step of the resumable traversal (the body of `traverse` / `bvh_walk`, cut at every node, leaf and op).
+__device__ __forceinline__ void trav_step(const DScene& S, Lane& L, Counters& C, int* __restrict__ stack, int stride, const double* __restrict__ cd, size_t nl, size_t lane) {
+  if (L.cur == CUR_NONE) {  // ---- op level
+    if (L.pc >= S.n_ops) { L.phase = PH_DONE; return; }
+    DOp op = S.ops[L.pc];
+    if (op.op == OP_PRIM) {
+      visit_prim(S, op.a, L.r, L.T, C, 0);
+      L.pc++;
+    } else if (op.op == OP_GROUP) {
+      C.group_tests++;
+      L.pc = group_box_hit(S.group_box + 6 * op.a, L.r) ? L.pc + 1 : op.b;
+    } else if (op.op == OP_MESH || op.op == OP_BVH) {
+      if (op.op == OP_MESH) { L.r = to_object(S.xf_inv + 12 * op.b, L.r); L.in_mesh = 1; }
+      L.ix = 1.0 / L.r.dx; L.iy = 1.0 / L.r.dy; L.iz = 1.0 / L.r.dz;
+      L.cur = op.a;
+      L.sp = 0;
+    } else if (op.op == OP_QUIRK) {
+      for (int i = op.a; i < op.a + op.b; i++) visit_prim(S, S.quirk_prim[i], L.r, L.T, C, 2);
+      L.pc++;
+    } else {
+      quirk_grid_scan(S, S.qgrids[op.a], L.r, L.T, C);
+      L.pc++;
+    }
+  } else if (L.cur >= 0) {  // ---- inner node
+    const DBvhNode* N = S.bvh + L.cur;
+    C.accel_nodes++;
+    double lo = L.T.tlo - ((L.T.tlo == -DINF) ? 0.0 : 1e-7 * fmax(fabs(L.T.tlo), 1.0));
+    double hi = (L.T.thi == DINF) ? DINF : L.T.thi + 1e-7 * fmax(fabs(L.T.thi), 1.0);
+    double n0, n1;
+    bool h0 = slab(N->lo0, N->hi0, L.r, L.ix, L.iy, L.iz, lo, hi, n0);
+    bool h1 = slab(N->lo1, N->hi1, L.r, L.ix, L.iy, L.iz, lo, hi, n1);
+    int c0 = N->c0, c1 = N->c1;
+    if (h0 && h1) {
+      if (n1 < n0) { int tmp = c0; c0 = c1; c1 = tmp; }
+      stack[L.sp * stride] = c1;
+      L.sp++;
+      L.cur = c0;
+    } else if (h0) L.cur = c0;
+    else if (h1) L.cur = c1;
+    else bvh_pop(L, stack, stride, cd, nl, lane);
+  } else {  // ---- leaf
+    int first = (~L.cur) >> 3, cnt = ((~L.cur) & 7) + 1;
+    if (L.in_mesh) {
+      for (int i = first; i < first + cnt; i++) {
+        double t, u, v;
+        C.tri_tests++;
+        if (tri_hit(S.mtri + 9 * (size_t)i, L.r, t, u, v)) accept(L.T, C, S.mtri_prim[i], 1, &t);
+      }
+    } else {
+      for (int i = first; i < first + cnt; i++) visit_prim(S, S.item_prim[i], L.r, L.T, C, 1);
+    }
+    bvh_pop(L, stack, stride, cd, nl, lane);
+  }
+  if (L.T.mode == MODE_SHADOW_ANY && L.T.shadowed) L.phase = PH_DONE;
+}
+
+__device__ __forceinline__ void start_traversal(Lane& L, double* __restrict__ cd, size_t nl, size_t lane) {
+  L.pc = 0; L.cur = CUR_NONE; L.sp = 0; L.in_mesh = 0;
+  L.phase = PH_TRAV;
+  ctx_store_ray(cd, nl, lane, CF_TRAY, L.r);
+}
+
+}  // namespace
+
+template <bool COUNT>
+__global__ void __launch_bounds__(RTC_WAVE, RTC_V2_WAVES_PER_SIMD) rtc_persist_kernel(DScene S, DCamera cam, DPixelMap pm, int fuel0, double* __restrict__ rgb,
+                                                                                   double* __restrict__ hit_t, int* __restrict__ hit_prim, int* __restrict__ hit_k,
+                                                                                   DStats* __restrict__ stats, unsigned long long* __restrict__ next_pixel,
+                                                                                   double* __restrict__ cd, int* __restrict__ ci) {
+  __shared__ int lds_stack[RTC_BVH_STACK * RTC_WAVE];
+  const int lid = threadIdx.x;  // one wave per block
+  int* stack = lds_stack + lid;
+  const int stride = RTC_WAVE;
+  const size_t nl = (size_t)gridDim.x * RTC_WAVE;
+  const size_t lane = (size_t)blockIdx.x * RTC_WAVE + lid;
+  const int pslots = fuel0 + 2;
+  Counters C = {0, 0, 0, 0, 0};
+  unsigned n_primary = 0, n_shadow = 0, n_reflect = 0, n_refract = 0, n_container = 0;
+  const double NL = (double)S.n_lights;
+
+  Lane L;
+  L.phase = PH_IDLE; L.stage = ST_CLOSEST; L.light = 0; L.fuel = 0; L.np = 0; L.kind = 0; L.q = 0;
+  L.pc = 0; L.cur = CUR_NONE; L.sp = 0; L.in_mesh = 0;
+  L.r.ox = L.r.oy = L.r.oz = L.r.dx = L.r.dy = L.r.dz = 0.0; L.ix = L.iy = L.iz = 0.0;
+  reset_closest(L.T, MODE_CLOSEST);
+  bool first_hit_pending = false;
+
+  for (;;) {
+    // ---------------------------------------------------------------- (a) refill idle lanes with new pixels
+    unsigned long long idle = __ballot(L.phase == PH_IDLE);
+    if (idle) {
+      int n = __popcll(idle);
+      unsigned long long base = 0;
+      int leader = __ffsll((long long)idle) - 1;
+      if (lid == leader) base = atomicAdd(next_pixel, (unsigned long long)n);
+      base = __shfl(base, leader);
+      if (L.phase == PH_IDLE) {
+        unsigned long long mine = base + (unsigned long long)__popcll(idle & ((1ull << lid) - 1ull));
+        if (mine < pm.n) {
+          L.q = (unsigned)mine;
+          if (pm.mode == 3) {
+            const double* rr = pm.rays + 6 * mine;
+            L.r.ox = rr[0]; L.r.oy = rr[1]; L.r.oz = rr[2]; L.r.dx = rr[3]; L.r.dy = rr[4]; L.r.dz = rr[5];
+          } else {
+            uint64_t i;
+            if (pm.mode == 0) i = pm.first + mine;
+            else if (pm.mode == 1) i = pm.indices[mine];
+            else i = ((uint64_t)pm.row_first + (mine / cam.hsize) * pm.row_step) * cam.hsize + (mine % cam.hsize);
+            L.r = camera_ray(cam, i);
+          }
+          cd[(CF_ACC + 0) * nl + lane] = 0.0; cd[(CF_ACC + 1) * nl + lane] = 0.0; cd[(CF_ACC + 2) * nl + lane] = 0.0;
+          cd[CF_WEIGHT * nl + lane] = 1.0;
+          L.fuel = fuel0; L.np = 0; L.kind = 0; L.stage = ST_CLOSEST;
+          first_hit_pending = true;
+          n_primary++;
+          reset_closest(L.T, MODE_CLOSEST);
+          ctx_store_ray(cd, nl, lane, CF_HRAY, L.r);
+          start_traversal(L, cd, nl, lane);
+        } else {
+          L.phase = PH_EXIT;
+        }
+      }
+    }
+    if (__ballot(L.phase != PH_EXIT) == 0ull) break;
+
+    // ---------------------------------------------------------------- (b) the shared traversal loop
+    for (;;) {
+      unsigned long long trav = __ballot(L.phase == PH_TRAV);
+      if (trav == 0ull) break;
+      int waiting = __popcll(__ballot(L.phase == PH_DONE));
+      if (waiting >= RTC_V2_WAIT_LANES) break;
+      if (L.phase == PH_TRAV) trav_step(S, L, C, stack, stride, cd, nl, lane);
+    }
+
+    // ---------------------------------------------------------------- (c) continuations of finished traversals
+    if (L.phase == PH_DONE) {
+      bool next_ray = false;   // fetch the next pending ray of this pixel (or finish the pixel)
+      bool prep = false;       // build the hit state and start the light loop
+      double n1 = 1.0, n2 = 1.0;
+      if (L.stage == ST_CLOSEST) {
+        bool did_hit = L.T.best_prim != 0x7fffffff;
+        if (first_hit_pending) {
+          first_hit_pending = false;
+          if (hit_t) {
+            hit_t[L.q] = did_hit ? L.T.best_t : 0.0;
+            hit_prim[L.q] = did_hit ? L.T.best_prim : -1;
+            hit_k[L.q] = did_hit ? L.T.best_k : 0;
+          }
+        }
+        if (!did_hit) next_ray = true;
+        else {
+          const DPrim P = S.prims[L.T.best_prim];
+          if (S.mat[8 * P.mat + 5] != 0.0) {  // transparency: n1/n2 are consumed -> container pass on the same ray
+            n_container++;
+            L.T.mode = MODE_CONTAINERS;
+            L.T.tlo = -DINF; L.T.thi = L.T.best_t;
+            L.T.c1_prim = -1; L.T.c2_prim = -1; L.T.c1_t = 0.0; L.T.c2_t = 0.0;
+            L.r = ctx_load_ray(cd, nl, lane, CF_HRAY);
+            L.stage = ST_CONT;
+            start_traversal(L, cd, nl, lane);
+          } else prep = true;
+        }
+      } else if (L.stage == ST_CONT) {
+        if (L.T.c1_prim >= 0) n1 = S.mat[8 * S.prims[L.T.c1_prim].mat + 6];
+        if (L.T.c2_prim >= 0) n2 = S.mat[8 * S.prims[L.T.c2_prim].mat + 6];
+        prep = true;
+      }
+
+      if (prep) {  // Intersection::prepare_state + Pattern::color_at, stored for the light loop
+        const DPrim P = S.prims[L.T.best_prim];
+        Ray hr = ctx_load_ray(cd, nl, lane, CF_HRAY);
+        double hu, hv;
+        hit_uv(S, P, hr, hu, hv);
+        State st;
+        prepare_state(S, P, hr, L.T.best_t, hu, hv, st);
+        double cr, cg, cb;
+        {
+          const double* mi = S.xf_matinv + 16 * P.xform;
+          double x = mi[0] * st.px + mi[1] * st.py + mi[2] * st.pz + mi[3] * 1.0;
+          double y = mi[4] * st.px + mi[5] * st.py + mi[6] * st.pz + mi[7] * 1.0;
+          double z = mi[8] * st.px + mi[9] * st.py + mi[10] * st.pz + mi[11] * 1.0;
+          double w = mi[12] * st.px + mi[13] * st.py + mi[14] * st.pz + mi[15] * 1.0;
+          const DPat& root = S.pats[S.mat_pattern[P.mat]];
+          if (root.tag == 1) { cr = root.color[0]; cg = root.color[1]; cb = root.color[2]; }
+          else pattern_color(S, S.mat_pattern[P.mat], x, y, z, w, cr, cg, cb);
+        }
+        // over_point / normal are what the light loop and the spawn step need; under_point and reflect are rebuilt there
+        cd[(CF_POINT + 0) * nl + lane] = hr.ox + hr.dx * L.T.best_t;
+        cd[(CF_POINT + 1) * nl + lane] = hr.oy + hr.dy * L.T.best_t;
+        cd[(CF_POINT + 2) * nl + lane] = hr.oz + hr.dz * L.T.best_t;
+        cd[(CF_NORMAL + 0) * nl + lane] = st.nx; cd[(CF_NORMAL + 1) * nl + lane] = st.ny; cd[(CF_NORMAL + 2) * nl + lane] = st.nz;
+        cd[(CF_COLOR + 0) * nl + lane] = cr; cd[(CF_COLOR + 1) * nl + lane] = cg; cd[(CF_COLOR + 2) * nl + lane] = cb;
+        cd[CF_N1 * nl + lane] = n1; cd[CF_N2 * nl + lane] = n2;
+        cd[CF_T * nl + lane] = L.T.best_t;
+        ci[CI_PRIM * nl + lane] = L.T.best_prim;
+        L.light = 0;
+        L.stage = ST_SHADOW;
+        if (S.n_lights == 0) L.light = -1;  // no lights: nothing to add, straight to the spawn step
+      }
+
+      bool spawn = false;
+      if (L.stage == ST_SHADOW && L.phase == PH_DONE && !next_ray) {
+        // hit state back from the context
+        const int hp = ci[CI_PRIM * nl + lane];
+        const DPrim P = S.prims[hp];
+        const double* M = S.mat + 8 * P.mat;
+        double qx = cd[(CF_POINT + 0) * nl + lane], qy = cd[(CF_POINT + 1) * nl + lane], qz = cd[(CF_POINT + 2) * nl + lane];
+        double nx = cd[(CF_NORMAL + 0) * nl + lane], ny = cd[(CF_NORMAL + 1) * nl + lane], nz = cd[(CF_NORMAL + 2) * nl + lane];
+        double opx = qx + nx * EPS, opy = qy + ny * EPS, opz = qz + nz * EPS;  // over_point
+        if (!prep && L.light >= 0) {
+          // a shadow traversal for light L.light just finished: Shape::lighting (src/shape.rs:429-462)
+          const double* LG = S.lights + 6 * L.light;
+          double vx = LG[3] - opx, vy = LG[4] - opy, vz = LG[5] - opz;
+          double distance = sqrt(vx * vx + vy * vy + vz * vz);
+          double ldx = vx / distance, ldy = vy / distance, ldz = vz / distance;
+          bool shadowed;
+          if (S.all_cast_shadow) shadowed = L.T.shadowed != 0;
+          else shadowed = (L.T.best_prim != 0x7fffffff) && (S.prims[L.T.best_prim].flags & 1u) && (L.T.best_t < distance);
+          double cr = cd[(CF_COLOR + 0) * nl + lane], cg = cd[(CF_COLOR + 1) * nl + lane], cb = cd[(CF_COLOR + 2) * nl + lane];
+          double er = cr * LG[0], eg = cg * LG[1], eb = cb * LG[2];
+          double lr = er * M[0], lg = eg * M[0], lb = eb * M[0];
+          double ldn = ldx * nx + ldy * ny + ldz * nz;
+          double dr = 0.0, dg = 0.0, db = 0.0, pr = 0.0, pg = 0.0, pb = 0.0;
+          if (!shadowed && ldn >= 0.0) {
+            dr = er * M[1] * ldn; dg = eg * M[1] * ldn; db = eb * M[1] * ldn;
+            double mlx = -ldx, mly = -ldy, mlz = -ldz;
+            double d2 = 2.0 * (mlx * nx + mly * ny + mlz * nz);
+            double rfx = mlx - nx * d2, rfy = mly - ny * d2, rfz = mlz - nz * d2;
+            double ex = -cd[(CF_HRAY + 3) * nl + lane], ey = -cd[(CF_HRAY + 4) * nl + lane], ez = -cd[(CF_HRAY + 5) * nl + lane];
+            double rde = rfx * ex + rfy * ey + rfz * ez;
+            if (rde > 0.0) {
+              double f = pow(rde, M[3]);
+              pr = LG[0] * M[2] * f; pg = LG[1] * M[2] * f; pb = LG[2] * M[2] * f;
+            }
+          }
+          double w = cd[CF_WEIGHT * nl + lane];
+          cd[(CF_ACC + 0) * nl + lane] += w * ((lr + dr) + pr);
+          cd[(CF_ACC + 1) * nl + lane] += w * ((lg + dg) + pg);
+          cd[(CF_ACC + 2) * nl + lane] += w * ((lb + db) + pb);
+          L.light++;
+        }
+        if (L.light >= 0 && L.light < S.n_lights) {
+          // World::is_shadowed (src/world.rs:26-48) for the next light
+          const double* LG = S.lights + 6 * L.light;
+          double vx = LG[3] - opx, vy = LG[4] - opy, vz = LG[5] - opz;
+          double distance = sqrt(vx * vx + vy * vy + vz * vz);
+          L.r.ox = opx; L.r.oy = opy; L.r.oz = opz;
+          L.r.dx = vx / distance; L.r.dy = vy / distance; L.r.dz = vz / distance;
+          n_shadow++;
+          reset_closest(L.T, S.all_cast_shadow ? MODE_SHADOW_ANY : MODE_SHADOW_CLOSEST);
+          if (S.all_cast_shadow) L.T.thi = distance;
+          start_traversal(L, cd, nl, lane);
+        } else spawn = true;
+
+        if (spawn) {  // reflected_color / refracted_color (src/world.rs:84-132) as weighted pending rays
+          double reflective = M[4], transparency = M[5];
+          if (L.fuel > 0 && (reflective != 0.0 || transparency != 0.0)) {
+            double w = cd[CF_WEIGHT * nl + lane];
+            double dx = cd[(CF_HRAY + 3) * nl + lane], dy = cd[(CF_HRAY + 4) * nl + lane], dz = cd[(CF_HRAY + 5) * nl + lane];
+            double ex = -dx, ey = -dy, ez = -dz;
+            bool do_refl = reflective != 0.0, do_refr = transparency != 0.0;
+            double wr = w * NL * reflective, wt = w * NL * transparency;
+            double m1 = cd[CF_N1 * nl + lane], m2 = cd[CF_N2 * nl + lane];
+            if (reflective > 0.0 && transparency > 0.0) {
+              State st;
+              st.ex = ex; st.ey = ey; st.ez = ez; st.nx = nx; st.ny = ny; st.nz = nz;
+              double R = schlick(st, m1, m2);
+              wr *= R;
+              wt *= (1.0 - R);
+            }
+            if (do_refr) {
+              double n_ratio = m1 / m2;
+              double cos_i = ex * nx + ey * ny + ez * nz;
+              double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
+              if (!(sin2_t > 1.0)) {
+                double cos_t = sqrt(1.0 - sin2_t);
+                double kk = n_ratio * cos_i - cos_t;
+                int s = L.np++;
+                size_t b = (size_t)(CF_PEND + 7 * s);
+                cd[(b + 0) * nl + lane] = qx - nx * EPS; cd[(b + 1) * nl + lane] = qy - ny * EPS; cd[(b + 2) * nl + lane] = qz - nz * EPS;  // under_point
+                cd[(b + 3) * nl + lane] = nx * kk - ex * n_ratio; cd[(b + 4) * nl + lane] = ny * kk - ey * n_ratio; cd[(b + 5) * nl + lane] = nz * kk - ez * n_ratio;
+                cd[(b + 6) * nl + lane] = wt;
+                ci[(CI_PEND + s) * nl + lane] = ((L.fuel - 1) << 2) | 2;
+              }
+            }
+            if (do_refl) {
+              double dn = 2.0 * (dx * nx + dy * ny + dz * nz);
+              int s = L.np++;
+              size_t b = (size_t)(CF_PEND + 7 * s);
+              cd[(b + 0) * nl + lane] = opx; cd[(b + 1) * nl + lane] = opy; cd[(b + 2) * nl + lane] = opz;
+              cd[(b + 3) * nl + lane] = dx - nx * dn; cd[(b + 4) * nl + lane] = dy - ny * dn; cd[(b + 5) * nl + lane] = dz - nz * dn;
+              cd[(b + 6) * nl + lane] = wr;
+              ci[(CI_PEND + s) * nl + lane] = ((L.fuel - 1) << 2) | 1;
+            }
+          }
+          next_ray = true;
+        }
+      }
+
+      if (next_ray) {
+        if (L.np > 0) {
+          int s = --L.np;
+          size_t b = (size_t)(CF_PEND + 7 * s);
+          L.r.ox = cd[(b + 0) * nl + lane]; L.r.oy = cd[(b + 1) * nl + lane]; L.r.oz = cd[(b + 2) * nl + lane];
+          L.r.dx = cd[(b + 3) * nl + lane]; L.r.dy = cd[(b + 4) * nl + lane]; L.r.dz = cd[(b + 5) * nl + lane];
+          cd[CF_WEIGHT * nl + lane] = cd[(b + 6) * nl + lane];
+          int fk = ci[(CI_PEND + s) * nl + lane];
+          L.fuel = fk >> 2; L.kind = fk & 3;
+          if (L.kind == 1) n_reflect++; else n_refract++;
+          L.stage = ST_CLOSEST;
+          reset_closest(L.T, MODE_CLOSEST);
+          ctx_store_ray(cd, nl, lane, CF_HRAY, L.r);
+          start_traversal(L, cd, nl, lane);
+        } else {
+          rgb[3 * (size_t)L.q + 0] = cd[(CF_ACC + 0) * nl + lane];
+          rgb[3 * (size_t)L.q + 1] = cd[(CF_ACC + 1) * nl + lane];
+          rgb[3 * (size_t)L.q + 2] = cd[(CF_ACC + 2) * nl + lane];
+          L.phase = PH_IDLE;
+        }
+      }
+    }
+    (void)pslots;
+  }
+
+  if (C.nan_ts) atomicAdd(&stats->nan_ts, (unsigned long long)C.nan_ts);
+  if (COUNT) {
+    atomicAdd(&stats->rays_primary, (unsigned long long)n_primary);
+    atomicAdd(&stats->rays_shadow, (unsigned long long)n_shadow);
+    atomicAdd(&stats->rays_reflect, (unsigned long long)n_reflect);
+    atomicAdd(&stats->rays_refract, (unsigned long long)n_refract);
+    atomicAdd(&stats->rays_container, (unsigned long long)n_container);
+    atomicAdd(&stats->accel_nodes, (unsigned long long)C.accel_nodes);
+    atomicAdd(&stats->group_tests, (unsigned long long)C.group_tests);
+    atomicAdd(&stats->tri_tests, (unsigned long long)C.tri_tests);
+    atomicAdd(&stats->analytic_tests, (unsigned long long)C.analytic_tests);
+  }
+}
+
+// Context sizes for a launch of `lanes` lanes at fuel `fuel` (pending slots: fuel + 2).
+size_t rtc_v2_ctx_doubles(size_t lanes, int fuel) { return (size_t)(CF_PEND + 7 * (fuel + 2)) * lanes; }
+size_t rtc_v2_ctx_ints(size_t lanes, int fuel) { return (size_t)(CI_PEND + (fuel + 2)) * lanes; }
+int rtc_v2_wave(void) { return RTC_WAVE; }
+
+#ifndef RTC_EMU
+// Resident waves per CU for the persistent kernel (occupancy query on the real code object).
+int rtc_v2_waves_per_cu(void) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtc_persist_kernel<false>, RTC_WAVE, 0) != hipSuccess || nb <= 0) nb = 4;
+  return nb;
+}
+#endif
+
+void rtc_launch_persist(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
+                        DStats* stats, bool count, unsigned n_waves, unsigned long long* next_pixel, double* ctx_d, int* ctx_i, hipStream_t stream) {
+  if (pm.n == 0 || n_waves == 0) return;
+  dim3 block(RTC_WAVE);
+  dim3 grid(n_waves);
+  if (count) hipLaunchKernelGGL(rtc_persist_kernel<true>, grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_pixel, ctx_d, ctx_i);
+  else hipLaunchKernelGGL(rtc_persist_kernel<false>, grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_pixel, ctx_d, ctx_i);
+}
+
 // ---- host-callable launcher (C++ linkage, used by rtc_scene.cpp) ------------------------------------------
 void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
                       DStats* stats, bool count, hipStream_t stream) {
   if (pm.n == 0) return;
-  dim3 block(256);
-  dim3 grid((unsigned)((pm.n + 255) / 256));
+  dim3 block(RTC_BLOCK);
+  dim3 grid((unsigned)((pm.n + RTC_BLOCK - 1) / RTC_BLOCK));
   if (count) hipLaunchKernelGGL(rtc_trace_kernel<true>, grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats);
   else hipLaunchKernelGGL(rtc_trace_kernel<false>, grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats);
 }

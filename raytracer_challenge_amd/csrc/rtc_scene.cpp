@@ -3,7 +3,9 @@
 // every entry point that computes pixels needs a HIP device and fails with RTC_ERR_DEVICE otherwise.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -16,6 +18,12 @@
 
 void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
                       DStats* stats, bool count, hipStream_t stream);
+void rtc_launch_persist(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
+                        DStats* stats, bool count, unsigned n_waves, unsigned long long* next_pixel, double* ctx_d, int* ctx_i, hipStream_t stream);
+size_t rtc_v2_ctx_doubles(size_t lanes, int fuel);
+size_t rtc_v2_ctx_ints(size_t lanes, int fuel);
+int rtc_v2_wave(void);
+int rtc_v2_waves_per_cu(void);
 
 static thread_local std::string g_rtc_err;
 static int rtc_fail(int code, const std::string& m) {
@@ -44,6 +52,13 @@ struct rtc_scene {
   uint64_t* d_idx = nullptr;
   double* d_rays = nullptr;
   uint64_t cap_px = 0, cap_idx = 0, cap_rays = 0;
+  // persistent kernel (v2): pixel counter + per-lane contexts
+  int kernel_version = 2;
+  unsigned long long* d_next = nullptr;
+  double* d_ctx_d = nullptr;
+  int* d_ctx_i = nullptr;
+  size_t cap_ctx_d = 0, cap_ctx_i = 0;
+  unsigned max_waves = 0;
   int bvh_depth = 0;
   uint32_t n_bvh_nodes = 0, n_mesh_tris = 0;
 
@@ -89,7 +104,32 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
   HIP_OK(hipSetDevice(s->device));
   HIP_OK(hipMemsetAsync(s->d_stats, 0, sizeof(DStats), s->stream));
   HIP_OK(hipEventRecord(s->ev0, s->stream));
-  rtc_launch_trace(s->d, cam, pm, fuel, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream);
+  if (s->kernel_version == 1) {
+    rtc_launch_trace(s->d, cam, pm, fuel, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream);
+  } else {
+    const unsigned wave = (unsigned)rtc_v2_wave();
+    uint64_t need_waves = (pm.n + wave - 1) / wave;
+    unsigned n_waves = (unsigned)std::min<uint64_t>(need_waves, s->max_waves);
+    size_t nd = rtc_v2_ctx_doubles((size_t)n_waves * wave, fuel), ni = rtc_v2_ctx_ints((size_t)n_waves * wave, fuel);
+    if (nd > s->cap_ctx_d) {
+      HIP_OK(hipStreamSynchronize(s->stream));
+      if (s->d_ctx_d) (void)hipFree(s->d_ctx_d);
+      s->d_ctx_d = nullptr; s->cap_ctx_d = 0;
+      HIP_OK(hipMalloc((void**)&s->d_ctx_d, nd * sizeof(double)));
+      s->cap_ctx_d = nd;
+    }
+    if (ni > s->cap_ctx_i) {
+      HIP_OK(hipStreamSynchronize(s->stream));
+      if (s->d_ctx_i) (void)hipFree(s->d_ctx_i);
+      s->d_ctx_i = nullptr; s->cap_ctx_i = 0;
+      HIP_OK(hipMalloc((void**)&s->d_ctx_i, ni * sizeof(int)));
+      s->cap_ctx_i = ni;
+    }
+    HIP_OK(hipMemsetAsync(s->d_next, 0, sizeof(unsigned long long), s->stream));
+    HIP_OK(hipEventRecord(s->ev0, s->stream));
+    rtc_launch_persist(s->d, cam, pm, fuel, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, n_waves, s->d_next,
+                       s->d_ctx_d, s->d_ctx_i, s->stream);
+  }
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(s->ev1, s->stream));
   if (!sync && !stats) return RTC_OK;
@@ -160,6 +200,17 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
   s->n_mesh_tris = (uint32_t)H.mtri_prim.size();
   HIP_OK(hipMalloc((void**)&s->d_stats, sizeof(DStats)));
   HIP_OK(hipMemset(s->d_stats, 0, sizeof(DStats)));
+  HIP_OK(hipMalloc((void**)&s->d_next, sizeof(unsigned long long)));
+  {
+    // RTC_KERNEL=1 selects the per-pixel kernel (v1) for A/B runs; both are HIP paths.
+    const char* kv = std::getenv("RTC_KERNEL");
+    s->kernel_version = (kv && kv[0] == '1') ? 1 : 2;
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, device));
+    int per_cu = rtc_v2_waves_per_cu();
+    if (const char* w = std::getenv("RTC_V2_WAVES_PER_CU")) per_cu = std::max(1, std::atoi(w));
+    s->max_waves = (unsigned)std::max(1, prop.multiProcessorCount * per_cu);
+  }
   *out = s.release();
   return RTC_OK;
 }
@@ -171,6 +222,9 @@ void rtc_scene_destroy(rtc_scene* s) {
   for (void* p : s->allocs) (void)hipFree(p);
   if (s->d_stats) (void)hipFree(s->d_stats);
   if (s->d_rgb) { (void)hipFree(s->d_rgb); (void)hipFree(s->d_hit_t); (void)hipFree(s->d_hit_prim); (void)hipFree(s->d_hit_k); }
+  if (s->d_next) (void)hipFree(s->d_next);
+  if (s->d_ctx_d) (void)hipFree(s->d_ctx_d);
+  if (s->d_ctx_i) (void)hipFree(s->d_ctx_i);
   if (s->d_idx) (void)hipFree(s->d_idx);
   if (s->d_rays) (void)hipFree(s->d_rays);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -197,7 +251,10 @@ int rtc_render(rtc_scene* s, const rtc_camera* cam, int32_t fuel, const uint64_t
     for (uint64_t i = 0; i < n; i++)
       if (pixel_indices[i] >= total) return rtc_fail(RTC_ERR_INVALID, "pixel index exceeds the image");
     if (n > s->cap_idx) {
-      if (s->d_idx) (void)hipFree(s->d_idx);
+      if (s->d_next) (void)hipFree(s->d_next);
+  if (s->d_ctx_d) (void)hipFree(s->d_ctx_d);
+  if (s->d_ctx_i) (void)hipFree(s->d_ctx_i);
+  if (s->d_idx) (void)hipFree(s->d_idx);
       s->d_idx = nullptr; s->cap_idx = 0;
       HIP_OK(hipMalloc((void**)&s->d_idx, n * sizeof(uint64_t)));
       s->cap_idx = n;

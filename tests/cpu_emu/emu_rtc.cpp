@@ -7,6 +7,8 @@
 
 #include "../../raytracer_challenge_amd/csrc/rtc_kernels.hip"
 
+#include <algorithm>
+#include <cstdlib>
 #include <memory>
 #include <string>
 #include <vector>
@@ -28,7 +30,16 @@ static int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double*
   std::vector<int> p(hits ? pm.n : 0), k(hits ? pm.n : 0);
   DStats st;
   std::memset(&st, 0, sizeof(st));
-  rtc_launch_trace(s->d, cam, pm, fuel, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr);
+  const char* kv = std::getenv("RTC_KERNEL");
+  if (kv && kv[0] == '1') {
+    rtc_launch_trace(s->d, cam, pm, fuel, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr);
+  } else {  // persistent kernel with one-lane "waves" (RTC_WAVE = 1): same lane-level state machine as on the GPU
+    unsigned n_waves = (unsigned)std::min<uint64_t>(pm.n, 7);
+    std::vector<double> cd(rtc_v2_ctx_doubles(n_waves, fuel));
+    std::vector<int> ci(rtc_v2_ctx_ints(n_waves, fuel));
+    unsigned long long next = 0;
+    rtc_launch_persist(s->d, cam, pm, fuel, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, n_waves, &next, cd.data(), ci.data(), nullptr);
+  }
   if (hits) for (uint64_t i = 0; i < pm.n; i++) hits[i] = {t[i], p[i], k[i]};
   if (stats) {
     std::memset(stats, 0, sizeof(*stats));

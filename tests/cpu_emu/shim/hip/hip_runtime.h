@@ -18,6 +18,11 @@ struct uint3_ { unsigned x, y, z; };
 static uint3_ blockIdx, threadIdx, blockDim, gridDim;
 typedef void* hipStream_t;
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+// wave intrinsics for a one-lane "wave" (the emulator builds the persistent kernel with RTC_WAVE = 1)
+static inline unsigned long long __ballot(int p) { return p ? 1ull : 0ull; }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+template <class T> static inline T __shfl(T v, int) { return v; }
 using std::fabs; using std::floor; using std::fmax; using std::fmin; using std::pow; using std::sqrt;
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)          \
   do {                                                                       \
