@@ -205,11 +205,13 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     // RTC_KERNEL=1 selects the per-pixel kernel (v1) for A/B runs; both are HIP paths.
     const char* kv = std::getenv("RTC_KERNEL");
     s->kernel_version = (kv && kv[0] == '1') ? 1 : 2;
-    hipDeviceProp_t prop;
-    HIP_OK(hipGetDeviceProperties(&prop, device));
+    // hipDeviceGetAttribute, not hipGetDeviceProperties: the property struct's layout differs between ROCm releases and
+    // this library may run on the HIP runtime PyTorch loaded first.
+    int n_cu = 0;
+    HIP_OK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device));
     int per_cu = rtc_v2_waves_per_cu();
     if (const char* w = std::getenv("RTC_V2_WAVES_PER_CU")) per_cu = std::max(1, std::atoi(w));
-    s->max_waves = (unsigned)std::max(1, prop.multiProcessorCount * per_cu);
+    s->max_waves = (unsigned)std::max(1, n_cu * per_cu);
   }
   *out = s.release();
   return RTC_OK;
