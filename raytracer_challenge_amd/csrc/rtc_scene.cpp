@@ -253,10 +253,7 @@ int rtc_render(rtc_scene* s, const rtc_camera* cam, int32_t fuel, const uint64_t
     for (uint64_t i = 0; i < n; i++)
       if (pixel_indices[i] >= total) return rtc_fail(RTC_ERR_INVALID, "pixel index exceeds the image");
     if (n > s->cap_idx) {
-      if (s->d_next) (void)hipFree(s->d_next);
-  if (s->d_ctx_d) (void)hipFree(s->d_ctx_d);
-  if (s->d_ctx_i) (void)hipFree(s->d_ctx_i);
-  if (s->d_idx) (void)hipFree(s->d_idx);
+      if (s->d_idx) (void)hipFree(s->d_idx);
       s->d_idx = nullptr; s->cap_idx = 0;
       HIP_OK(hipMalloc((void**)&s->d_idx, n * sizeof(uint64_t)));
       s->cap_idx = n;
