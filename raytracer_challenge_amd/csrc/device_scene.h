@@ -84,6 +84,7 @@ struct DScene {
   const double* lights;      // n_lights x {intensity rgb, origin xyz}
   int32_t n_ops, n_prims, n_lights;
   int32_t all_cast_shadow;   // 1: every primitive casts a shadow -> shadow rays may stop at any hit
+  int32_t has_mesh;          // 1: the program contains an OP_MESH
 };
 
 // Which pixels a launch covers.

@@ -908,11 +908,17 @@ struct Lane {  // register-resident state of one lane
   Ray r;              // ray in the space of the structure being walked (world, or object space inside OP_MESH)
   double ix, iy, iz;  // 1/direction while inside a BVH
   Trav T;
-  int pc, cur, sp;    // program counter, BVH cursor (CUR_NONE = at op level), stack depth
+  int pc, cur, sp;    // program counter, BVH cursor (CUR_NONE = at op level, CUR_END = BVH drained), stack depth
+  int it, it_end, it_kind;  // pending leaf / list items [it, it_end) and where their primitive ids come from
   int in_mesh;        // r is an object-space ray
   int phase, stage, light, fuel, np, kind;
   unsigned q;         // output slot of the pixel in flight
+  double acc_r, acc_g, acc_b, weight;
 };
+#define CUR_END ((int)0x80000001)
+enum { IT_DIRECT = 0, IT_BVHITEM = 1, IT_QLIN = 2, IT_QGRID = 3, IT_TRI = 4 };
+// What a traversing lane wants to do next; the wave runs one kind per iteration (the most wanted one).
+enum { K_NONE = 0, K_OP = 1, K_INNER = 2, K_PRIM = 3, K_TRI = 4 };
 
 __device__ __forceinline__ void ctx_store_ray(double* __restrict__ cd, size_t nl, size_t lane, int f, const Ray& r) {
   cd[(f + 0) * nl + lane] = r.ox; cd[(f + 1) * nl + lane] = r.oy; cd[(f + 2) * nl + lane] = r.oz;
@@ -925,78 +931,117 @@ __device__ __forceinline__ Ray ctx_load_ray(const double* __restrict__ cd, size_
   return r;
 }
 
-// Leave the BVH the lane is in: next op; back to the world-space ray if it was inside a mesh.
-__device__ __forceinline__ void bvh_exit(Lane& L, const double* __restrict__ cd, size_t nl, size_t lane) {
-  L.cur = CUR_NONE;
-  L.pc++;
-  if (L.in_mesh) { L.r = ctx_load_ray(cd, nl, lane, CF_TRAY); L.in_mesh = 0; }
-}
-__device__ __forceinline__ void bvh_pop(Lane& L, const int* __restrict__ stack, int stride, const double* __restrict__ cd, size_t nl, size_t lane) {
-  if (L.sp == 0) { bvh_exit(L, cd, nl, lane); return; }
+__device__ __forceinline__ int bvh_pop(Lane& L, const int* __restrict__ stack, int stride) {
+  if (L.sp == 0) return CUR_END;
   L.sp--;
-  L.cur = stack[L.sp * stride];
+  return stack[L.sp * stride];
 }
 
-// One step of the resumable traversal (the body of `traverse` / `bvh_walk`, cut at every node, leaf and op).
-__device__ __forceinline__ void trav_step(const DScene& S, Lane& L, Counters& C, int* __restrict__ stack, int stride, const double* __restrict__ cd, size_t nl, size_t lane) {
-  if (L.cur == CUR_NONE) {  // ---- op level
-    if (L.pc >= S.n_ops) { L.phase = PH_DONE; return; }
-    DOp op = S.ops[L.pc];
-    if (op.op == OP_PRIM) {
-      visit_prim(S, op.a, L.r, L.T, C, 0);
-      L.pc++;
-    } else if (op.op == OP_GROUP) {
-      C.group_tests++;
-      L.pc = group_box_hit(S.group_box + 6 * op.a, L.r) ? L.pc + 1 : op.b;
-    } else if (op.op == OP_MESH || op.op == OP_BVH) {
-      if (op.op == OP_MESH) { L.r = to_object(S.xf_inv + 12 * op.b, L.r); L.in_mesh = 1; }
-      L.ix = 1.0 / L.r.dx; L.iy = 1.0 / L.r.dy; L.iz = 1.0 / L.r.dz;
-      L.cur = op.a;
-      L.sp = 0;
-    } else if (op.op == OP_QUIRK) {
-      for (int i = op.a; i < op.a + op.b; i++) visit_prim(S, S.quirk_prim[i], L.r, L.T, C, 2);
-      L.pc++;
-    } else {
-      quirk_grid_scan(S, S.qgrids[op.a], L.r, L.T, C);
-      L.pc++;
-    }
-  } else if (L.cur >= 0) {  // ---- inner node
-    const DBvhNode* N = S.bvh + L.cur;
-    C.accel_nodes++;
-    double lo = L.T.tlo - ((L.T.tlo == -DINF) ? 0.0 : 1e-7 * fmax(fabs(L.T.tlo), 1.0));
-    double hi = (L.T.thi == DINF) ? DINF : L.T.thi + 1e-7 * fmax(fabs(L.T.thi), 1.0);
-    double n0, n1;
-    bool h0 = slab(N->lo0, N->hi0, L.r, L.ix, L.iy, L.iz, lo, hi, n0);
-    bool h1 = slab(N->lo1, N->hi1, L.r, L.ix, L.iy, L.iz, lo, hi, n1);
-    int c0 = N->c0, c1 = N->c1;
-    if (h0 && h1) {
-      if (n1 < n0) { int tmp = c0; c0 = c1; c1 = tmp; }
-      stack[L.sp * stride] = c1;
-      L.sp++;
-      L.cur = c0;
-    } else if (h0) L.cur = c0;
-    else if (h1) L.cur = c1;
-    else bvh_pop(L, stack, stride, cd, nl, lane);
-  } else {  // ---- leaf
+// A leaf reference in the cursor becomes a pending item range; the cursor moves on to the next stack entry.
+__device__ __forceinline__ void unpack_leaf(Lane& L, const int* __restrict__ stack, int stride) {
+  if (L.it >= L.it_end && L.cur < 0 && L.cur != CUR_NONE && L.cur != CUR_END) {
     int first = (~L.cur) >> 3, cnt = ((~L.cur) & 7) + 1;
-    if (L.in_mesh) {
-      for (int i = first; i < first + cnt; i++) {
-        double t, u, v;
-        C.tri_tests++;
-        if (tri_hit(S.mtri + 9 * (size_t)i, L.r, t, u, v)) accept(L.T, C, S.mtri_prim[i], 1, &t);
-      }
-    } else {
-      for (int i = first; i < first + cnt; i++) visit_prim(S, S.item_prim[i], L.r, L.T, C, 1);
-    }
-    bvh_pop(L, stack, stride, cd, nl, lane);
+    L.it = first; L.it_end = first + cnt;
+    L.it_kind = L.in_mesh ? IT_TRI : IT_BVHITEM;
+    L.cur = bvh_pop(L, stack, stride);
   }
-  if (L.T.mode == MODE_SHADOW_ANY && L.T.shadowed) L.phase = PH_DONE;
+}
+__device__ __forceinline__ int lane_kind(const Lane& L) {
+  if (L.phase != PH_TRAV) return K_NONE;
+  if (L.it < L.it_end) return L.it_kind == IT_TRI ? K_TRI : K_PRIM;
+  if (L.cur >= 0) return K_INNER;
+  if (L.cur == CUR_NONE || L.cur == CUR_END) return K_OP;
+  return K_NONE;  // a leaf ref waiting for unpack_leaf (next iteration)
 }
 
-__device__ __forceinline__ void start_traversal(Lane& L, double* __restrict__ cd, size_t nl, size_t lane) {
-  L.pc = 0; L.cur = CUR_NONE; L.sp = 0; L.in_mesh = 0;
+// K_OP: leave a drained BVH, or dispatch the next op of the program.
+__device__ __forceinline__ void step_op(const DScene& S, Lane& L, Counters& C, const double* __restrict__ cd, size_t nl, size_t lane) {
+  if (L.cur == CUR_END) {
+    L.cur = CUR_NONE;
+    L.pc++;
+    if (L.in_mesh) { L.r = ctx_load_ray(cd, nl, lane, CF_TRAY); L.in_mesh = 0; }
+    return;
+  }
+  if (L.pc >= S.n_ops) { L.phase = PH_DONE; return; }
+  DOp op = S.ops[L.pc];
+  if (op.op == OP_PRIM) {
+    L.it = op.a; L.it_end = op.a + 1; L.it_kind = IT_DIRECT;
+    L.pc++;
+  } else if (op.op == OP_GROUP) {
+    C.group_tests++;
+    L.pc = group_box_hit(S.group_box + 6 * op.a, L.r) ? L.pc + 1 : op.b;
+  } else if (op.op == OP_MESH || op.op == OP_BVH) {
+    if (op.op == OP_MESH) { L.r = to_object(S.xf_inv + 12 * op.b, L.r); L.in_mesh = 1; }
+    L.ix = 1.0 / L.r.dx; L.iy = 1.0 / L.r.dy; L.iz = 1.0 / L.r.dz;
+    L.cur = op.a;
+    L.sp = 0;
+  } else if (op.op == OP_QUIRK) {
+    L.it = op.a; L.it_end = op.a + op.b; L.it_kind = IT_QLIN;
+    L.pc++;
+  } else {  // OP_QGRID: the cell lookup of quirk_grid_scan, items deferred to K_PRIM steps
+    const DQuirkGrid G = S.qgrids[op.a];
+    const Ray& r = L.r;
+    double ax = fabs(r.dx), ay = fabs(r.dy), az = fabs(r.dz);
+    double len2 = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
+    if (!(len2 >= RTC_QGRID_MIN_LEN * RTC_QGRID_MIN_LEN) || !(len2 < DINF)) {
+      L.it = G.lin_first; L.it_end = G.lin_first + G.lin_count; L.it_kind = IT_QLIN;
+    } else {
+      int face;
+      double u, v;
+      if (ax >= ay && ax >= az) { face = r.dx > 0.0 ? 0 : 1; u = r.dy / ax; v = r.dz / ax; }
+      else if (ay >= az) { face = r.dy > 0.0 ? 2 : 3; u = r.dx / ay; v = r.dz / ay; }
+      else { face = r.dz > 0.0 ? 4 : 5; u = r.dx / az; v = r.dy / az; }
+      int iu = (int)((u + 1.0) * 0.5 * (double)G.n), iv = (int)((v + 1.0) * 0.5 * (double)G.n);
+      iu = iu < 0 ? 0 : (iu >= G.n ? G.n - 1 : iu);
+      iv = iv < 0 ? 0 : (iv >= G.n ? G.n - 1 : iv);
+      int cell = G.cell_off + (face * G.n + iv) * G.n + iu;
+      L.it = (int)S.qcell[cell]; L.it_end = (int)S.qcell[cell + 1]; L.it_kind = IT_QGRID;
+    }
+    L.pc++;
+  }
+}
+
+// K_INNER: one BVH node (both children's slabs).
+__device__ __forceinline__ void step_inner(const DScene& S, Lane& L, Counters& C, int* __restrict__ stack, int stride) {
+  const DBvhNode* N = S.bvh + L.cur;
+  C.accel_nodes++;
+  double lo = L.T.tlo - ((L.T.tlo == -DINF) ? 0.0 : 1e-7 * fmax(fabs(L.T.tlo), 1.0));
+  double hi = (L.T.thi == DINF) ? DINF : L.T.thi + 1e-7 * fmax(fabs(L.T.thi), 1.0);
+  double n0, n1;
+  bool h0 = slab(N->lo0, N->hi0, L.r, L.ix, L.iy, L.iz, lo, hi, n0);
+  bool h1 = slab(N->lo1, N->hi1, L.r, L.ix, L.iy, L.iz, lo, hi, n1);
+  int c0 = N->c0, c1 = N->c1;
+  if (h0 && h1) {
+    if (n1 < n0) { int tmp = c0; c0 = c1; c1 = tmp; }
+    stack[L.sp * stride] = c1;
+    L.sp++;
+    L.cur = c0;
+  } else if (h0) L.cur = c0;
+  else if (h1) L.cur = c1;
+  else L.cur = bvh_pop(L, stack, stride);
+}
+
+// K_PRIM: one analytic primitive (exact test, own matrix).  K_TRI: one packed mesh triangle in object space.
+__device__ __forceinline__ void step_prim(const DScene& S, Lane& L, Counters& C) {
+  int prim, policy;
+  if (L.it_kind == IT_DIRECT) { prim = L.it; policy = 0; }
+  else if (L.it_kind == IT_BVHITEM) { prim = S.item_prim[L.it]; policy = 1; }
+  else if (L.it_kind == IT_QLIN) { prim = S.quirk_prim[L.it]; policy = 2; }
+  else { prim = S.qitem[L.it]; policy = 2; }
+  L.it++;
+  visit_prim(S, prim, L.r, L.T, C, policy);
+}
+__device__ __forceinline__ void step_tri(const DScene& S, Lane& L, Counters& C) {
+  double t, u, v;
+  int i = L.it++;
+  C.tri_tests++;
+  if (tri_hit(S.mtri + 9 * (size_t)i, L.r, t, u, v)) accept(L.T, C, S.mtri_prim[i], 1, &t);
+}
+
+__device__ __forceinline__ void start_traversal(const DScene& S, Lane& L, double* __restrict__ cd, size_t nl, size_t lane) {
+  L.pc = 0; L.cur = CUR_NONE; L.sp = 0; L.in_mesh = 0; L.it = 0; L.it_end = 0; L.it_kind = IT_DIRECT;
   L.phase = PH_TRAV;
-  ctx_store_ray(cd, nl, lane, CF_TRAY, L.r);
+  if (S.has_mesh) ctx_store_ray(cd, nl, lane, CF_TRAY, L.r);  // only a mesh walk replaces L.r by an object-space ray
 }
 
 }  // namespace
@@ -1019,7 +1064,8 @@ __global__ void __launch_bounds__(RTC_WAVE, RTC_V2_WAVES_PER_SIMD) rtc_persist_k
 
   Lane L;
   L.phase = PH_IDLE; L.stage = ST_CLOSEST; L.light = 0; L.fuel = 0; L.np = 0; L.kind = 0; L.q = 0;
-  L.pc = 0; L.cur = CUR_NONE; L.sp = 0; L.in_mesh = 0;
+  L.pc = 0; L.cur = CUR_NONE; L.sp = 0; L.in_mesh = 0; L.it = 0; L.it_end = 0; L.it_kind = IT_DIRECT;
+  L.acc_r = L.acc_g = L.acc_b = 0.0; L.weight = 1.0;
   L.r.ox = L.r.oy = L.r.oz = L.r.dx = L.r.dy = L.r.dz = 0.0; L.ix = L.iy = L.iz = 0.0;
   reset_closest(L.T, MODE_CLOSEST);
   bool first_hit_pending = false;
@@ -1047,14 +1093,13 @@ __global__ void __launch_bounds__(RTC_WAVE, RTC_V2_WAVES_PER_SIMD) rtc_persist_k
             else i = ((uint64_t)pm.row_first + (mine / cam.hsize) * pm.row_step) * cam.hsize + (mine % cam.hsize);
             L.r = camera_ray(cam, i);
           }
-          cd[(CF_ACC + 0) * nl + lane] = 0.0; cd[(CF_ACC + 1) * nl + lane] = 0.0; cd[(CF_ACC + 2) * nl + lane] = 0.0;
-          cd[CF_WEIGHT * nl + lane] = 1.0;
+          L.acc_r = 0.0; L.acc_g = 0.0; L.acc_b = 0.0; L.weight = 1.0;
           L.fuel = fuel0; L.np = 0; L.kind = 0; L.stage = ST_CLOSEST;
           first_hit_pending = true;
           n_primary++;
           reset_closest(L.T, MODE_CLOSEST);
           ctx_store_ray(cd, nl, lane, CF_HRAY, L.r);
-          start_traversal(L, cd, nl, lane);
+          start_traversal(S, L, cd, nl, lane);
         } else {
           L.phase = PH_EXIT;
         }
@@ -1063,12 +1108,27 @@ __global__ void __launch_bounds__(RTC_WAVE, RTC_V2_WAVES_PER_SIMD) rtc_persist_k
     if (__ballot(L.phase != PH_EXIT) == 0ull) break;
 
     // ---------------------------------------------------------------- (b) the shared traversal loop
+    // One homogeneous step kind per iteration, chosen by ballot: the kind most lanes are waiting for.
     for (;;) {
+      unpack_leaf(L, stack, stride);
+      int kd = lane_kind(L);
       unsigned long long trav = __ballot(L.phase == PH_TRAV);
       if (trav == 0ull) break;
-      int waiting = __popcll(__ballot(L.phase == PH_DONE));
-      if (waiting >= RTC_V2_WAIT_LANES) break;
-      if (L.phase == PH_TRAV) trav_step(S, L, C, stack, stride, cd, nl, lane);
+      if (__popcll(__ballot(L.phase == PH_DONE)) >= RTC_V2_WAIT_LANES) break;
+      int c_inner = __popcll(__ballot(kd == K_INNER)), c_prim = __popcll(__ballot(kd == K_PRIM));
+      int c_tri = __popcll(__ballot(kd == K_TRI)), c_op = __popcll(__ballot(kd == K_OP));
+      int pick = K_INNER, best = c_inner;
+      if (c_tri > best) { pick = K_TRI; best = c_tri; }
+      if (c_prim > best) { pick = K_PRIM; best = c_prim; }
+      if (c_op > best) { pick = K_OP; best = c_op; }
+      if (best == 0) continue;  // only leaf refs pending: unpack_leaf turns them into items next iteration
+      if (kd == pick) {
+        if (pick == K_INNER) step_inner(S, L, C, stack, stride);
+        else if (pick == K_TRI) step_tri(S, L, C);
+        else if (pick == K_PRIM) step_prim(S, L, C);
+        else step_op(S, L, C, cd, nl, lane);
+        if (L.T.mode == MODE_SHADOW_ANY && L.T.shadowed) { L.phase = PH_DONE; L.it = 0; L.it_end = 0; }
+      }
     }
 
     // ---------------------------------------------------------------- (c) continuations of finished traversals
@@ -1096,7 +1156,7 @@ __global__ void __launch_bounds__(RTC_WAVE, RTC_V2_WAVES_PER_SIMD) rtc_persist_k
             L.T.c1_prim = -1; L.T.c2_prim = -1; L.T.c1_t = 0.0; L.T.c2_t = 0.0;
             L.r = ctx_load_ray(cd, nl, lane, CF_HRAY);
             L.stage = ST_CONT;
-            start_traversal(L, cd, nl, lane);
+            start_traversal(S, L, cd, nl, lane);
           } else prep = true;
         }
       } else if (L.stage == ST_CONT) {
@@ -1172,10 +1232,9 @@ __global__ void __launch_bounds__(RTC_WAVE, RTC_V2_WAVES_PER_SIMD) rtc_persist_k
               pr = LG[0] * M[2] * f; pg = LG[1] * M[2] * f; pb = LG[2] * M[2] * f;
             }
           }
-          double w = cd[CF_WEIGHT * nl + lane];
-          cd[(CF_ACC + 0) * nl + lane] += w * ((lr + dr) + pr);
-          cd[(CF_ACC + 1) * nl + lane] += w * ((lg + dg) + pg);
-          cd[(CF_ACC + 2) * nl + lane] += w * ((lb + db) + pb);
+          L.acc_r += L.weight * ((lr + dr) + pr);
+          L.acc_g += L.weight * ((lg + dg) + pg);
+          L.acc_b += L.weight * ((lb + db) + pb);
           L.light++;
         }
         if (L.light >= 0 && L.light < S.n_lights) {
@@ -1188,13 +1247,13 @@ __global__ void __launch_bounds__(RTC_WAVE, RTC_V2_WAVES_PER_SIMD) rtc_persist_k
           n_shadow++;
           reset_closest(L.T, S.all_cast_shadow ? MODE_SHADOW_ANY : MODE_SHADOW_CLOSEST);
           if (S.all_cast_shadow) L.T.thi = distance;
-          start_traversal(L, cd, nl, lane);
+          start_traversal(S, L, cd, nl, lane);
         } else spawn = true;
 
         if (spawn) {  // reflected_color / refracted_color (src/world.rs:84-132) as weighted pending rays
           double reflective = M[4], transparency = M[5];
           if (L.fuel > 0 && (reflective != 0.0 || transparency != 0.0)) {
-            double w = cd[CF_WEIGHT * nl + lane];
+            double w = L.weight;
             double dx = cd[(CF_HRAY + 3) * nl + lane], dy = cd[(CF_HRAY + 4) * nl + lane], dz = cd[(CF_HRAY + 5) * nl + lane];
             double ex = -dx, ey = -dy, ez = -dz;
             bool do_refl = reflective != 0.0, do_refr = transparency != 0.0;
@@ -1242,18 +1301,18 @@ __global__ void __launch_bounds__(RTC_WAVE, RTC_V2_WAVES_PER_SIMD) rtc_persist_k
           size_t b = (size_t)(CF_PEND + 7 * s);
           L.r.ox = cd[(b + 0) * nl + lane]; L.r.oy = cd[(b + 1) * nl + lane]; L.r.oz = cd[(b + 2) * nl + lane];
           L.r.dx = cd[(b + 3) * nl + lane]; L.r.dy = cd[(b + 4) * nl + lane]; L.r.dz = cd[(b + 5) * nl + lane];
-          cd[CF_WEIGHT * nl + lane] = cd[(b + 6) * nl + lane];
+          L.weight = cd[(b + 6) * nl + lane];
           int fk = ci[(CI_PEND + s) * nl + lane];
           L.fuel = fk >> 2; L.kind = fk & 3;
           if (L.kind == 1) n_reflect++; else n_refract++;
           L.stage = ST_CLOSEST;
           reset_closest(L.T, MODE_CLOSEST);
           ctx_store_ray(cd, nl, lane, CF_HRAY, L.r);
-          start_traversal(L, cd, nl, lane);
+          start_traversal(S, L, cd, nl, lane);
         } else {
-          rgb[3 * (size_t)L.q + 0] = cd[(CF_ACC + 0) * nl + lane];
-          rgb[3 * (size_t)L.q + 1] = cd[(CF_ACC + 1) * nl + lane];
-          rgb[3 * (size_t)L.q + 2] = cd[(CF_ACC + 2) * nl + lane];
+          rgb[3 * (size_t)L.q + 0] = L.acc_r;
+          rgb[3 * (size_t)L.q + 1] = L.acc_g;
+          rgb[3 * (size_t)L.q + 2] = L.acc_b;
           L.phase = PH_IDLE;
         }
       }

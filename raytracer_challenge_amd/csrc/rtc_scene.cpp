@@ -195,6 +195,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
   d.n_prims = (int32_t)H.prims.size();
   d.n_lights = H.n_lights;
   d.all_cast_shadow = H.all_cast_shadow;
+  d.has_mesh = H.view().has_mesh;
   s->bvh_depth = H.bvh_depth;
   s->n_bvh_nodes = (uint32_t)H.bvh.size();
   s->n_mesh_tris = (uint32_t)H.mtri_prim.size();

@@ -326,6 +326,8 @@ struct HostArrays {
     d.tri_geo = tri_geo.data(); d.tri_nrm = tri_nrm.data(); d.mat = mat.data(); d.mat_pattern = mat_pattern.data(); d.pats = pats.data();
     d.lights = lights.data();
     d.n_ops = (int32_t)ops.size(); d.n_prims = (int32_t)prims.size(); d.n_lights = n_lights; d.all_cast_shadow = all_cast_shadow;
+    d.has_mesh = 0;
+    for (const DOp& o : ops) if (o.op == OP_MESH) d.has_mesh = 1;
     return d;
   }
 };

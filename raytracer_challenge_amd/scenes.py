@@ -204,3 +204,56 @@ def synthetic_analytic(n_primitives=512, seed=12345, cones=False, grouped=False,
                    PointLight(Color.new(0.7, 0.7, 0.7), Vector.point(100.0, 100.0, -100.0))],
                   [floor, left, right] + body)
     return _cam(1920, 1080, 1.4, (0.0, 30.0, -50.0), (0.0, 0.0, 10.0), (0.0, 1.0, 0.0), hsize, vsize), world
+
+
+def write_heightfield_obj(path: str, nx: int, nz: int, seed: int = 12345) -> int:
+    """Writes a displaced nx x nz vertex grid as ONE OBJ group with analytic smooth normals
+    (`f a//a b//b c//c`, two triangles per cell) and returns the triangle count.  The surface is
+    y = sum of three seeded sine waves over x, z in [-20, 20]; deterministic for (nx, nz, seed)."""
+    import numpy as np
+    rng = SplitMix64(seed)
+    waves = [(rng.uniform(0.15, 0.5), rng.uniform(0.15, 0.5), rng.uniform(0.0, 2 * PI), rng.uniform(0.4, 1.2)) for _ in range(3)]
+    xs = np.linspace(-20.0, 20.0, nx)
+    zs = np.linspace(-20.0, 20.0, nz)
+    X, Z = np.meshgrid(xs, zs, indexing="xy")  # (nz, nx)
+    Y = np.zeros_like(X)
+    dYdx = np.zeros_like(X)
+    dYdz = np.zeros_like(X)
+    for (kx, kz, ph, amp) in waves:
+        arg = kx * X + kz * Z + ph
+        Y += amp * np.sin(arg)
+        dYdx += amp * kx * np.cos(arg)
+        dYdz += amp * kz * np.cos(arg)
+    N = np.stack([-dYdx, np.ones_like(X), -dYdz], axis=-1)
+    N /= np.linalg.norm(N, axis=-1, keepdims=True)
+    V = np.stack([X, Y, Z], axis=-1).reshape(-1, 3)
+    Nf = N.reshape(-1, 3)
+    idx = (np.arange(nz - 1)[:, None] * nx + np.arange(nx - 1)[None, :]).reshape(-1) + 1  # 1-based index of each cell's corner
+    a, b, c, d = idx, idx + 1, idx + nx, idx + nx + 1
+    tris = np.concatenate([np.stack([a, c, b], axis=1), np.stack([b, c, d], axis=1)], axis=0)
+    with open(path, "w") as f:
+        f.write("# synthetic heightfield %dx%d seed %d\ng Heightfield\n" % (nx, nz, seed))
+        np.savetxt(f, V, fmt="v %.17g %.17g %.17g")
+        np.savetxt(f, Nf, fmt="vn %.17g %.17g %.17g")
+        np.savetxt(f, np.concatenate([tris, tris], axis=1)[:, [0, 3, 1, 4, 2, 5]], fmt="f %d//%d %d//%d %d//%d")
+    return int(tris.shape[0])
+
+
+def synthetic_mesh(obj_path: str, nx: int = 708, nz: int = 708, seed: int = 12345, hsize: int = 3840, vsize: int = 2160) -> Tuple[Camera, World]:
+    """BASELINE config 5: a ~10^6-triangle synthetic smooth mesh (708 x 708 grid -> 999 698 triangles)
+    with `point_jitter(Fractal{0.3, 4}, stripes)`, a second object with `Noise::Simplex{0.3}`, reflective 0.1, floor plane,
+    two lights; 4K, fuel 8.  `obj_path` is written if it does not exist (the reference's on-disk format is the interface)."""
+    if not os.path.exists(obj_path):
+        write_heightfield_obj(obj_path, nx, nz, seed)
+    mesh_mat = Material(pattern=Pattern.point_jitter(Noise.Fractal(0.3, 4), Pattern.stripes(Matrix.scaling(0.7, 0.7, 0.7), Pattern.plain(Color.new(0.9, 0.85, 0.6)), Pattern.plain(Color.new(0.3, 0.45, 0.25)))),
+                        diffuse=0.8, specular=0.2, shininess=20.0, reflective=0.1)
+    mesh = Element.obj(obj_path, Matrix.translation(0.0, 2.0, 10.0), mesh_mat)
+    ball = Element.sphere(ShapeArgs(transform=Matrix.translation(-6.0, 9.0, 2.0) * Matrix.scaling(3.0, 3.0, 3.0), material=Material(
+        pattern=Pattern.point_jitter(Noise.Simplex(0.3), Pattern.checkers(Matrix.scaling(0.4, 0.4, 0.4), Pattern.plain(Color.new(0.9, 0.2, 0.2)), Pattern.plain(Color.white()))),
+        reflective=0.1)))
+    glass = Element.sphere(ShapeArgs(transform=Matrix.translation(7.0, 8.0, 0.0) * Matrix.scaling(2.5, 2.5, 2.5), material=Material(
+        pattern=Pattern.plain(Color.new(0.05, 0.05, 0.1)), diffuse=0.2, transparency=0.9, reflective=0.9, refractive_index=1.5)))
+    floor = Element.plane(ShapeArgs(transform=Matrix.translation(0.0, -3.0, 0.0), material=Material(pattern=Pattern.plain(Color.new(0.2, 0.2, 0.25)), reflective=0.3, specular=0.0)))
+    world = World([PointLight(Color.new(0.7, 0.7, 0.7), Vector.point(-100.0, 100.0, -100.0)), PointLight(Color.new(0.5, 0.5, 0.5), Vector.point(60.0, 80.0, -40.0))],
+                  [floor, mesh, ball, glass])
+    return _cam(3840, 2160, 1.2, (0.0, 22.0, -32.0), (0.0, 2.0, 8.0), (0.0, 1.0, 0.0), hsize, vsize), world

@@ -26,7 +26,8 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
         acc, n = defaultdict(float), defaultdict(int)
         for row in csv.DictReader(open(f)):
-            if "rtc_trace_kernel<false>" not in row.get("Kernel_Name", ""):
+            kn = row.get("Kernel_Name", "")
+            if "rtc_trace_kernel<false>" not in kn and "rtc_persist_kernel<false>" not in kn:
                 continue
             acc[row["Counter_Name"]] += float(row["Counter_Value"])
             n[row["Counter_Name"]] += 1

@@ -1,5 +1,6 @@
 """Scene cases shared by the CPU (emulated-kernel) and GPU parity tests.  Each returns (camera, world)."""
 import math
+import os
 
 import numpy as np
 
@@ -104,6 +105,16 @@ def cube_lattice():
     return _cam(64, 48, 1.0, (0.0, 0.0, -14.0), (0, 0, 0)), World([PointLight(Color.white(), Vector.point(-8, 12, -12))], els)
 
 
+def synthetic_mesh_small():
+    """Config-5 shaped scene at test size: 40x40 heightfield (3 042 smooth triangles, one OBJ group) with Fractal/Simplex
+    point-jitter materials, a glass sphere, two lights."""
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), "rtc_heightfield_40x40_12345.obj")
+    if not os.path.exists(path):
+        scenes.write_heightfield_obj(path, 40, 40, 12345)
+    return scenes.synthetic_mesh(path, hsize=48, vsize=27)
+
+
 def edge_rays(n=4096, seed=7):
     """Rays for color_at parity: random, axis-parallel (the |d|<EPSILON slab rule), grazing, starting inside shapes, zero-ish components."""
     rng = np.random.default_rng(seed)
@@ -134,4 +145,5 @@ SMALL_CASES = {
     "patterns_and_noise": patterns_and_noise,
     "nested_groups": nested_groups,
     "cube_lattice": cube_lattice,
+    "synthetic_mesh_small": synthetic_mesh_small,
 }

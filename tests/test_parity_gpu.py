@@ -78,3 +78,36 @@ def test_hip_rows_device_matches_host_path(hip):
         got = out.cpu().numpy().reshape(-1, 3)
         want = full.reshape(cam.vsize, cam.hsize, 3)[rows].reshape(-1, 3)
         assert np.array_equal(got, want), (step, first)
+
+
+def test_hip_config4_teapot_high_4k_fuel8(hip, orc):
+    """BASELINE configs[3] on one GPU: teapot_high.obj (6 320 smooth triangles), 3840x2160, fuel 8 — full frame on the HIP path,
+    a strided sample against the oracle (which tests every triangle of the flat group, src/shape.rs:254-256)."""
+    cam, world = scenes.chapter15_teapot("teapot_high.obj", 3840, 2160)
+    nw = hip.build_world(world)
+    rgb, hits = hip.render(nw, cam, 8)
+    assert np.isfinite(rgb).all() and (hits["prim"] < nw.primitive_count).all()
+    on_teapot = np.flatnonzero(hits["prim"] >= 3)
+    assert on_teapot.size > 100000
+    idx = np.concatenate([np.arange(0, 3840 * 2160, 41011), on_teapot[::4001]]).astype(np.uint64)
+    assert_parity(hip, orc, world, cam, 8, idx, label="config4 sample (%d px)" % idx.size)
+
+
+def test_hip_config5_million_triangles_noise(hip, orc, tmp_path):
+    """BASELINE configs[4] on one GPU: ~10^6-triangle smooth mesh (one OBJ group) with Fractal/Simplex procedural textures,
+    3840x2160, fuel 8.  Full frame on the HIP path; oracle parity on a small pixel sample at fuel 5 (the oracle tests
+    10^6 triangles per ray that enters the group's box); full-size property: index-list render == full-range render."""
+    path = str(tmp_path / "heightfield_708.obj")
+    ntri = scenes.write_heightfield_obj(path, 708, 708, 12345)
+    assert ntri == 999698
+    cam, world = scenes.synthetic_mesh(path)
+    nw = hip.build_world(world)
+    assert nw.primitive_count == ntri + 3
+    rgb, hits = hip.render(nw, cam, 8)
+    assert np.isfinite(rgb).all()
+    on_mesh = np.flatnonzero((hits["prim"] >= 1) & (hits["prim"] <= ntri))
+    assert on_mesh.size > 1000000
+    idx = np.concatenate([np.arange(1000, 3840 * 2160, 3840 * 2160 // 24), on_mesh[:: on_mesh.size // 24]]).astype(np.uint64)
+    rgb2, hits2 = hip.render(nw, cam, 8, idx)
+    assert np.array_equal(rgb2, rgb[idx.astype(np.int64)]) and np.array_equal(hits2, hits[idx.astype(np.int64)])
+    assert_parity(hip, orc, world, cam, 5, idx, label="config5 sample (%d px)" % idx.size)
