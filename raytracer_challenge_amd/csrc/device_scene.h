@@ -85,6 +85,8 @@ struct DScene {
   int32_t n_ops, n_prims, n_lights;
   int32_t all_cast_shadow;   // 1: every primitive casts a shadow -> shadow rays may stop at any hit
   int32_t has_mesh;          // 1: the program contains an OP_MESH
+  // array lengths, for the traversal guards (a bad index retires the lane and raises DStats.guard instead of faulting)
+  int32_t n_bvh, n_items, n_mtri, n_quirk, n_qitem, n_qcell, n_groups, n_qgrids;
 };
 
 // Which pixels a launch covers.
@@ -106,6 +108,7 @@ struct DCamera {
 struct DStats {  // device-side counters (atomically accumulated per wave)
   unsigned long long rays_primary, rays_shadow, rays_reflect, rays_refract, rays_container;
   unsigned long long accel_nodes, group_tests, tri_tests, analytic_tests, nan_ts;
+  unsigned long long guard;  // bit mask of tripped traversal guards (0 = none)
 };
 
 #define RTC_MAX_FUEL 16

@@ -26,7 +26,7 @@
 #define RTC_WAVES_PER_SIMD 1
 #endif
 #ifndef RTC_V2_WAVES_PER_SIMD
-#define RTC_V2_WAVES_PER_SIMD 1
+#define RTC_V2_WAVES_PER_SIMD 2
 #endif
 #ifdef RTC_TRAVERSE_NOINLINE
 #define TRAVERSE_INLINE __noinline__
@@ -931,6 +931,15 @@ __device__ __forceinline__ Ray ctx_load_ray(const double* __restrict__ cd, size_
   return r;
 }
 
+// Traversal guards: every index a step is about to use is checked against its array; on a violation the lane's
+// traversal is retired (as if the program had ended) and a bit is raised in DStats.guard -> the host reports
+// RTC_ERR_DEVICE instead of the GPU faulting.
+enum { G_NODE = 0, G_ITEM = 1, G_TRI = 2, G_PRIM = 3, G_OP = 4, G_STACK = 5, G_QUIRK = 6 };
+__device__ __forceinline__ void guard_trip(Lane& L, const DScene& S, unsigned& gmask, int code) {
+  gmask |= 1u << code;
+  L.cur = CUR_NONE; L.pc = S.n_ops; L.it = 0; L.it_end = 0; L.sp = 0; L.in_mesh = 0;
+}
+
 __device__ __forceinline__ int bvh_pop(Lane& L, const int* __restrict__ stack, int stride) {
   if (L.sp == 0) return CUR_END;
   L.sp--;
@@ -955,7 +964,7 @@ __device__ __forceinline__ int lane_kind(const Lane& L) {
 }
 
 // K_OP: leave a drained BVH, or dispatch the next op of the program.
-__device__ __forceinline__ void step_op(const DScene& S, Lane& L, Counters& C, const double* __restrict__ cd, size_t nl, size_t lane) {
+__device__ __forceinline__ void step_op(const DScene& S, Lane& L, Counters& C, const double* __restrict__ cd, size_t nl, size_t lane, unsigned& gmask) {
   if (L.cur == CUR_END) {
     L.cur = CUR_NONE;
     L.pc++;
@@ -963,6 +972,7 @@ __device__ __forceinline__ void step_op(const DScene& S, Lane& L, Counters& C, c
     return;
   }
   if (L.pc >= S.n_ops) { L.phase = PH_DONE; return; }
+  if (L.pc < 0) { guard_trip(L, S, gmask, G_OP); return; }
   DOp op = S.ops[L.pc];
   if (op.op == OP_PRIM) {
     L.it = op.a; L.it_end = op.a + 1; L.it_kind = IT_DIRECT;
@@ -979,6 +989,7 @@ __device__ __forceinline__ void step_op(const DScene& S, Lane& L, Counters& C, c
     L.it = op.a; L.it_end = op.a + op.b; L.it_kind = IT_QLIN;
     L.pc++;
   } else {  // OP_QGRID: the cell lookup of quirk_grid_scan, items deferred to K_PRIM steps
+    if ((unsigned)op.a >= (unsigned)S.n_qgrids) { guard_trip(L, S, gmask, G_QUIRK); return; }
     const DQuirkGrid G = S.qgrids[op.a];
     const Ray& r = L.r;
     double ax = fabs(r.dx), ay = fabs(r.dy), az = fabs(r.dz);
@@ -995,6 +1006,7 @@ __device__ __forceinline__ void step_op(const DScene& S, Lane& L, Counters& C, c
       iu = iu < 0 ? 0 : (iu >= G.n ? G.n - 1 : iu);
       iv = iv < 0 ? 0 : (iv >= G.n ? G.n - 1 : iv);
       int cell = G.cell_off + (face * G.n + iv) * G.n + iu;
+      if ((unsigned)(cell + 1) >= (unsigned)S.n_qcell) { guard_trip(L, S, gmask, G_QUIRK); return; }
       L.it = (int)S.qcell[cell]; L.it_end = (int)S.qcell[cell + 1]; L.it_kind = IT_QGRID;
     }
     L.pc++;
@@ -1002,7 +1014,8 @@ __device__ __forceinline__ void step_op(const DScene& S, Lane& L, Counters& C, c
 }
 
 // K_INNER: one BVH node (both children's slabs).
-__device__ __forceinline__ void step_inner(const DScene& S, Lane& L, Counters& C, int* __restrict__ stack, int stride) {
+__device__ __forceinline__ void step_inner(const DScene& S, Lane& L, Counters& C, int* __restrict__ stack, int stride, unsigned& gmask) {
+  if ((unsigned)L.cur >= (unsigned)S.n_bvh) { guard_trip(L, S, gmask, G_NODE); return; }
   const DBvhNode* N = S.bvh + L.cur;
   C.accel_nodes++;
   double lo = L.T.tlo - ((L.T.tlo == -DINF) ? 0.0 : 1e-7 * fmax(fabs(L.T.tlo), 1.0));
@@ -1013,6 +1026,7 @@ __device__ __forceinline__ void step_inner(const DScene& S, Lane& L, Counters& C
   int c0 = N->c0, c1 = N->c1;
   if (h0 && h1) {
     if (n1 < n0) { int tmp = c0; c0 = c1; c1 = tmp; }
+    if (L.sp >= RTC_BVH_STACK) { guard_trip(L, S, gmask, G_STACK); return; }
     stack[L.sp * stride] = c1;
     L.sp++;
     L.cur = c0;
@@ -1022,17 +1036,22 @@ __device__ __forceinline__ void step_inner(const DScene& S, Lane& L, Counters& C
 }
 
 // K_PRIM: one analytic primitive (exact test, own matrix).  K_TRI: one packed mesh triangle in object space.
-__device__ __forceinline__ void step_prim(const DScene& S, Lane& L, Counters& C) {
+__device__ __forceinline__ void step_prim(const DScene& S, Lane& L, Counters& C, unsigned& gmask) {
   int prim, policy;
+  const unsigned i = (unsigned)L.it;
+  const unsigned lim = L.it_kind == IT_DIRECT ? (unsigned)S.n_prims : L.it_kind == IT_BVHITEM ? (unsigned)S.n_items : L.it_kind == IT_QLIN ? (unsigned)S.n_quirk : (unsigned)S.n_qitem;
+  if (i >= lim) { guard_trip(L, S, gmask, G_ITEM); return; }
   if (L.it_kind == IT_DIRECT) { prim = L.it; policy = 0; }
   else if (L.it_kind == IT_BVHITEM) { prim = S.item_prim[L.it]; policy = 1; }
   else if (L.it_kind == IT_QLIN) { prim = S.quirk_prim[L.it]; policy = 2; }
   else { prim = S.qitem[L.it]; policy = 2; }
   L.it++;
+  if ((unsigned)prim >= (unsigned)S.n_prims) { guard_trip(L, S, gmask, G_PRIM); return; }
   visit_prim(S, prim, L.r, L.T, C, policy);
 }
-__device__ __forceinline__ void step_tri(const DScene& S, Lane& L, Counters& C) {
+__device__ __forceinline__ void step_tri(const DScene& S, Lane& L, Counters& C, unsigned& gmask) {
   double t, u, v;
+  if ((unsigned)L.it >= (unsigned)S.n_mtri) { guard_trip(L, S, gmask, G_TRI); return; }
   int i = L.it++;
   C.tri_tests++;
   if (tri_hit(S.mtri + 9 * (size_t)i, L.r, t, u, v)) accept(L.T, C, S.mtri_prim[i], 1, &t);
@@ -1069,6 +1088,7 @@ __global__ void __launch_bounds__(RTC_WAVE, RTC_V2_WAVES_PER_SIMD) rtc_persist_k
   L.r.ox = L.r.oy = L.r.oz = L.r.dx = L.r.dy = L.r.dz = 0.0; L.ix = L.iy = L.iz = 0.0;
   reset_closest(L.T, MODE_CLOSEST);
   bool first_hit_pending = false;
+  unsigned gmask = 0;
 
   for (;;) {
     // ---------------------------------------------------------------- (a) refill idle lanes with new pixels
@@ -1123,10 +1143,10 @@ __global__ void __launch_bounds__(RTC_WAVE, RTC_V2_WAVES_PER_SIMD) rtc_persist_k
       if (c_op > best) { pick = K_OP; best = c_op; }
       if (best == 0) continue;  // only leaf refs pending: unpack_leaf turns them into items next iteration
       if (kd == pick) {
-        if (pick == K_INNER) step_inner(S, L, C, stack, stride);
-        else if (pick == K_TRI) step_tri(S, L, C);
-        else if (pick == K_PRIM) step_prim(S, L, C);
-        else step_op(S, L, C, cd, nl, lane);
+        if (pick == K_INNER) step_inner(S, L, C, stack, stride, gmask);
+        else if (pick == K_TRI) step_tri(S, L, C, gmask);
+        else if (pick == K_PRIM) step_prim(S, L, C, gmask);
+        else step_op(S, L, C, cd, nl, lane, gmask);
         if (L.T.mode == MODE_SHADOW_ANY && L.T.shadowed) { L.phase = PH_DONE; L.it = 0; L.it_end = 0; }
       }
     }
@@ -1321,6 +1341,7 @@ __global__ void __launch_bounds__(RTC_WAVE, RTC_V2_WAVES_PER_SIMD) rtc_persist_k
   }
 
   if (C.nan_ts) atomicAdd(&stats->nan_ts, (unsigned long long)C.nan_ts);
+  if (gmask) atomicOr(&stats->guard, (unsigned long long)gmask);
   if (COUNT) {
     atomicAdd(&stats->rays_primary, (unsigned long long)n_primary);
     atomicAdd(&stats->rays_shadow, (unsigned long long)n_shadow);

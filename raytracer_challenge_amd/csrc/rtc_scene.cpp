@@ -147,6 +147,7 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
     stats->kernel_ms = ms;
     stats->n_launches = 1;
   }
+  if (h.guard) return rtc_fail(RTC_ERR_DEVICE, "traversal guard tripped (mask " + std::to_string(h.guard) + "): an index left its array; no pixel of this call is trustworthy");
   if (h.nan_ts) return rtc_fail(RTC_ERR_NAN, "a NaN intersection t was produced (the reference panics in Intersection::sort, src/intersection.rs:124)");
   return RTC_OK;
 }
@@ -195,7 +196,12 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
   d.n_prims = (int32_t)H.prims.size();
   d.n_lights = H.n_lights;
   d.all_cast_shadow = H.all_cast_shadow;
-  d.has_mesh = H.view().has_mesh;
+  {
+    DScene hv = H.view();
+    d.has_mesh = hv.has_mesh;
+    d.n_bvh = hv.n_bvh; d.n_items = hv.n_items; d.n_mtri = hv.n_mtri; d.n_quirk = hv.n_quirk;
+    d.n_qitem = hv.n_qitem; d.n_qcell = hv.n_qcell; d.n_groups = hv.n_groups; d.n_qgrids = hv.n_qgrids;
+  }
   s->bvh_depth = H.bvh_depth;
   s->n_bvh_nodes = (uint32_t)H.bvh.size();
   s->n_mesh_tris = (uint32_t)H.mtri_prim.size();

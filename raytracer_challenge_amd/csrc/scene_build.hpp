@@ -326,6 +326,8 @@ struct HostArrays {
     d.tri_geo = tri_geo.data(); d.tri_nrm = tri_nrm.data(); d.mat = mat.data(); d.mat_pattern = mat_pattern.data(); d.pats = pats.data();
     d.lights = lights.data();
     d.n_ops = (int32_t)ops.size(); d.n_prims = (int32_t)prims.size(); d.n_lights = n_lights; d.all_cast_shadow = all_cast_shadow;
+    d.n_bvh = (int32_t)bvh.size(); d.n_items = (int32_t)item_prim.size(); d.n_mtri = (int32_t)mtri_prim.size(); d.n_quirk = (int32_t)quirk_prim.size();
+    d.n_qitem = (int32_t)qitem.size(); d.n_qcell = (int32_t)qcell.size(); d.n_groups = (int32_t)(group_box.size() / 6); d.n_qgrids = (int32_t)qgrids.size();
     d.has_mesh = 0;
     for (const DOp& o : ops) if (o.op == OP_MESH) d.has_mesh = 1;
     return d;

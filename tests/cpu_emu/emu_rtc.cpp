@@ -35,8 +35,8 @@ static int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double*
     rtc_launch_trace(s->d, cam, pm, fuel, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr);
   } else {  // persistent kernel with one-lane "waves" (RTC_WAVE = 1): same lane-level state machine as on the GPU
     unsigned n_waves = (unsigned)std::min<uint64_t>(pm.n, 7);
-    std::vector<double> cd(rtc_v2_ctx_doubles(n_waves, fuel));
-    std::vector<int> ci(rtc_v2_ctx_ints(n_waves, fuel));
+    std::vector<double> cd(rtc_v2_ctx_doubles((size_t)n_waves * rtc_v2_wave(), fuel));
+    std::vector<int> ci(rtc_v2_ctx_ints((size_t)n_waves * rtc_v2_wave(), fuel));
     unsigned long long next = 0;
     rtc_launch_persist(s->d, cam, pm, fuel, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, n_waves, &next, cd.data(), ci.data(), nullptr);
   }
@@ -49,6 +49,7 @@ static int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double*
     stats->analytic_tests = st.analytic_tests; stats->nan_ts = st.nan_ts;
     stats->n_launches = 1;
   }
+  if (st.guard) return efail(RTC_ERR_DEVICE, "traversal guard tripped (mask " + std::to_string(st.guard) + ")");
   if (st.nan_ts) return efail(RTC_ERR_NAN, "NaN intersection t");
   return RTC_OK;
 }
