@@ -935,8 +935,14 @@ __device__ __forceinline__ Ray ctx_load_ray(const double* __restrict__ cd, size_
 // traversal is retired (as if the program had ended) and a bit is raised in DStats.guard -> the host reports
 // RTC_ERR_DEVICE instead of the GPU faulting.
 enum { G_NODE = 0, G_ITEM = 1, G_TRI = 2, G_PRIM = 3, G_OP = 4, G_STACK = 5, G_QUIRK = 6 };
-__device__ __forceinline__ void guard_trip(Lane& L, const DScene& S, unsigned& gmask, int code) {
+__device__ DStats* g_guard_stats = nullptr;
+__device__ __forceinline__ void guard_trip(Lane& L, const DScene& S, unsigned& gmask, int code, long long value = 0) {
   gmask |= 1u << code;
+  DStats* st = g_guard_stats;
+  if (st && atomicAdd(&st->guard_claim, 1ull) == 0ull) {
+    st->guard_info[0] = code; st->guard_info[1] = L.it_kind; st->guard_info[2] = L.it; st->guard_info[3] = L.it_end;
+    st->guard_info[4] = value; st->guard_info[5] = L.cur; st->guard_info[6] = L.pc; st->guard_info[7] = L.T.mode;
+  }
   L.cur = CUR_NONE; L.pc = S.n_ops; L.it = 0; L.it_end = 0; L.sp = 0; L.in_mesh = 0;
 }
 
@@ -1039,14 +1045,13 @@ __device__ __forceinline__ void step_inner(const DScene& S, Lane& L, Counters& C
 __device__ __forceinline__ void step_prim(const DScene& S, Lane& L, Counters& C, unsigned& gmask) {
   int prim, policy;
   const unsigned i = (unsigned)L.it;
-  const unsigned lim = L.it_kind == IT_DIRECT ? (unsigned)S.n_prims : L.it_kind == IT_BVHITEM ? (unsigned)S.n_items : L.it_kind == IT_QLIN ? (unsigned)S.n_quirk : (unsigned)S.n_qitem;
-  if (i >= lim) { guard_trip(L, S, gmask, G_ITEM); return; }
-  if (L.it_kind == IT_DIRECT) { prim = L.it; policy = 0; }
-  else if (L.it_kind == IT_BVHITEM) { prim = S.item_prim[L.it]; policy = 1; }
-  else if (L.it_kind == IT_QLIN) { prim = S.quirk_prim[L.it]; policy = 2; }
-  else { prim = S.qitem[L.it]; policy = 2; }
+  const bool direct = L.it_kind == IT_DIRECT;
+  if (i >= (direct ? (unsigned)S.n_prims : (unsigned)S.n_items)) { guard_trip(L, S, gmask, G_ITEM); return; }
+  // item_prim, quirk_prim and qitem are one array (absolute indices): only the policy depends on the item kind
+  prim = direct ? L.it : S.item_prim[direct ? 0 : L.it];
+  policy = direct ? 0 : (L.it_kind == IT_BVHITEM ? 1 : 2);
   L.it++;
-  if ((unsigned)prim >= (unsigned)S.n_prims) { guard_trip(L, S, gmask, G_PRIM); return; }
+  if ((unsigned)prim >= (unsigned)S.n_prims) { L.it--; guard_trip(L, S, gmask, G_PRIM, prim); return; }
   visit_prim(S, prim, L.r, L.T, C, policy);
 }
 __device__ __forceinline__ void step_tri(const DScene& S, Lane& L, Counters& C, unsigned& gmask) {
@@ -1089,6 +1094,7 @@ __global__ void __launch_bounds__(RTC_WAVE, RTC_V2_WAVES_PER_SIMD) rtc_persist_k
   reset_closest(L.T, MODE_CLOSEST);
   bool first_hit_pending = false;
   unsigned gmask = 0;
+  g_guard_stats = stats;  // same value from every lane
 
   for (;;) {
     // ---------------------------------------------------------------- (a) refill idle lanes with new pixels

@@ -147,7 +147,12 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
     stats->kernel_ms = ms;
     stats->n_launches = 1;
   }
-  if (h.guard) return rtc_fail(RTC_ERR_DEVICE, "traversal guard tripped (mask " + std::to_string(h.guard) + "): an index left its array; no pixel of this call is trustworthy");
+  if (h.guard) {
+    std::string info;
+    for (int i = 0; i < 8; i++) info += " " + std::to_string(h.guard_info[i]);
+    return rtc_fail(RTC_ERR_DEVICE, "traversal guard tripped (mask " + std::to_string(h.guard) + "; first: code it_kind it it_end value cur pc mode =" + info +
+                                        "): an index left its array; no pixel of this call is trustworthy");
+  }
   if (h.nan_ts) return rtc_fail(RTC_ERR_NAN, "a NaN intersection t was produced (the reference panics in Intersection::sort, src/intersection.rs:124)");
   return RTC_OK;
 }
@@ -189,7 +194,13 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     int rc_ = s->upload(H.field, &d.field);                             \
     if (rc_ != RTC_OK) { rtc_scene_destroy(s.release()); return rc_; } \
   } while (0)
-  UP(ops); UP(group_box); UP(bvh); UP(mtri); UP(mtri_prim); UP(item_prim); UP(quirk_prim); UP(qgrids); UP(qcell); UP(qitem); UP(prims); UP(xf_inv); UP(xf_matinv); UP(limits);
+  UP(ops); UP(group_box); UP(bvh); UP(mtri); UP(mtri_prim); {
+    int rc_ = s->upload(H.items, &d.item_prim);
+    if (rc_ != RTC_OK) { rtc_scene_destroy(s.release()); return rc_; }
+    d.quirk_prim = d.item_prim;
+    d.qitem = d.item_prim;
+  }
+  UP(qgrids); UP(qcell); UP(prims); UP(xf_inv); UP(xf_matinv); UP(limits);
   UP(tri_geo); UP(tri_nrm); UP(mat); UP(mat_pattern); UP(pats); UP(lights);
 #undef UP
   d.n_ops = (int32_t)H.ops.size();
@@ -205,6 +216,19 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
   s->bvh_depth = H.bvh_depth;
   s->n_bvh_nodes = (uint32_t)H.bvh.size();
   s->n_mesh_tris = (uint32_t)H.mtri_prim.size();
+  if (std::getenv("RTC_VERIFY_UPLOAD")) {  // debug aid: read every table back and compare with the host copy
+    auto verify = [&](const char* name, const void* dev, const void* host, size_t bytes) {
+      if (!bytes) return true;
+      std::vector<unsigned char> back(bytes);
+      if (hipMemcpy(back.data(), dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) return false;
+      if (std::memcmp(back.data(), host, bytes) != 0) { std::fprintf(stderr, "[rtc] upload mismatch in %s (%zu bytes)\n", name, bytes); return false; }
+      return true;
+    };
+    bool ok = verify("items", d.item_prim, H.items.data(), H.items.size() * 4);
+    ok = verify("qcell", d.qcell, H.qcell.data(), H.qcell.size() * 4) && ok;
+    ok = verify("ops", d.ops, H.ops.data(), H.ops.size() * sizeof(DOp)) && ok;
+    std::fprintf(stderr, "[rtc] upload verify: %s; n_items=%zu n_qcell=%zu n_prims=%zu\n", ok ? "ok" : "MISMATCH", H.items.size(), H.qcell.size(), H.prims.size());
+  }
   HIP_OK(hipMalloc((void**)&s->d_stats, sizeof(DStats)));
   HIP_OK(hipMemset(s->d_stats, 0, sizeof(DStats)));
   HIP_OK(hipMalloc((void**)&s->d_next, sizeof(unsigned long long)));

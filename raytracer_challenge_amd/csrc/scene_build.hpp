@@ -23,7 +23,10 @@ struct ProgramBuilder {
   std::vector<double> group_box;
   std::vector<DBvhNode> bvh_nodes;
   std::vector<double> mtri;
-  std::vector<int32_t> mtri_prim, item_prim, quirk_prim, qitem;
+  // ONE item array serves BVH leaves, linear quirk lists and direction-grid cells (absolute indices): a traversal
+  // step never has to choose between arrays.
+  std::vector<int32_t> mtri_prim, items;
+  std::vector<int32_t>&item_prim = items, &quirk_prim = items, &qitem = items;
   std::vector<DQuirkGrid> qgrids;
   std::vector<uint32_t> qcell;
   int max_depth = 0;
@@ -309,7 +312,7 @@ struct HostArrays {
   std::vector<double> group_box;
   std::vector<DBvhNode> bvh;
   std::vector<double> mtri;
-  std::vector<int32_t> mtri_prim, item_prim, quirk_prim, qitem;
+  std::vector<int32_t> mtri_prim, items;  // items: BVH leaf items + quirk lists + grid cells, absolute indices
   std::vector<DQuirkGrid> qgrids;
   std::vector<uint32_t> qcell;
   std::vector<DPrim> prims;
@@ -322,12 +325,12 @@ struct HostArrays {
   DScene view() const {
     DScene d{};
     d.ops = ops.data(); d.group_box = group_box.data(); d.bvh = bvh.data(); d.mtri = mtri.data(); d.mtri_prim = mtri_prim.data();
-    d.item_prim = item_prim.data(); d.quirk_prim = quirk_prim.data(); d.qgrids = qgrids.data(); d.qcell = qcell.data(); d.qitem = qitem.data(); d.prims = prims.data(); d.xf_inv = xf_inv.data(); d.xf_matinv = xf_matinv.data(); d.limits = limits.data();
+    d.item_prim = items.data(); d.quirk_prim = items.data(); d.qgrids = qgrids.data(); d.qcell = qcell.data(); d.qitem = items.data(); d.prims = prims.data(); d.xf_inv = xf_inv.data(); d.xf_matinv = xf_matinv.data(); d.limits = limits.data();
     d.tri_geo = tri_geo.data(); d.tri_nrm = tri_nrm.data(); d.mat = mat.data(); d.mat_pattern = mat_pattern.data(); d.pats = pats.data();
     d.lights = lights.data();
     d.n_ops = (int32_t)ops.size(); d.n_prims = (int32_t)prims.size(); d.n_lights = n_lights; d.all_cast_shadow = all_cast_shadow;
-    d.n_bvh = (int32_t)bvh.size(); d.n_items = (int32_t)item_prim.size(); d.n_mtri = (int32_t)mtri_prim.size(); d.n_quirk = (int32_t)quirk_prim.size();
-    d.n_qitem = (int32_t)qitem.size(); d.n_qcell = (int32_t)qcell.size(); d.n_groups = (int32_t)(group_box.size() / 6); d.n_qgrids = (int32_t)qgrids.size();
+    d.n_bvh = (int32_t)bvh.size(); d.n_items = (int32_t)items.size(); d.n_mtri = (int32_t)mtri_prim.size(); d.n_quirk = (int32_t)items.size();
+    d.n_qitem = (int32_t)items.size(); d.n_qcell = (int32_t)qcell.size(); d.n_groups = (int32_t)(group_box.size() / 6); d.n_qgrids = (int32_t)qgrids.size();
     d.has_mesh = 0;
     for (const DOp& o : ops) if (o.op == OP_MESH) d.has_mesh = 1;
     return d;
@@ -388,11 +391,9 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
   H->bvh = std::move(pb.bvh_nodes);
   H->mtri = std::move(pb.mtri);
   H->mtri_prim = std::move(pb.mtri_prim);
-  H->item_prim = std::move(pb.item_prim);
-  H->quirk_prim = std::move(pb.quirk_prim);
+  H->items = std::move(pb.items);
   H->qgrids = std::move(pb.qgrids);
   H->qcell = std::move(pb.qcell);
-  H->qitem = std::move(pb.qitem);
   H->bvh_depth = pb.max_depth;
   return RTC_OK;
 }
