@@ -690,31 +690,81 @@ __device__ __forceinline__ Ray camera_ray(const DCamera& cam, uint64_t i) {
   return r;
 }
 
+
+
+// Pixel slots.  A launch covers `pm.n` output slots.  With tiling (full-width pixel sets: mode 0 with whole rows, mode 2) the
+// work items are enumerated tile by tile (8x8 pixels, 64 consecutive work ids = one tile) so that the lanes of a wave,
+// and the pixels a lane fetches later, stay spatially close; a work id that falls outside the image is skipped.
+struct WorkMap {
+  uint64_t n_work;      // number of work ids
+  uint32_t tiled, tiles_x, width, height;
+};
+__device__ __forceinline__ WorkMap make_workmap(const DPixelMap& pm, const DCamera& cam) {
+  WorkMap w;
+  w.tiled = 0; w.tiles_x = 0; w.width = 0; w.height = 0; w.n_work = pm.n;
+  if ((pm.mode == 0 || pm.mode == 2) && cam.hsize >= 8 && pm.n % cam.hsize == 0 && (pm.mode == 2 || pm.first % cam.hsize == 0)) {
+    w.tiled = 1;
+    w.width = (uint32_t)cam.hsize;
+    w.height = (uint32_t)(pm.n / cam.hsize);
+    w.tiles_x = (w.width + 7u) / 8u;
+    w.n_work = (uint64_t)w.tiles_x * ((w.height + 7u) / 8u) * 64u;
+  }
+  return w;
+}
+// work id -> output slot q (row-major within the launch's pixel set); false if the id is padding.
+__device__ __forceinline__ bool work_to_slot(const WorkMap& w, uint64_t id, uint64_t& q) {
+  if (!w.tiled) { q = id; return true; }
+  uint64_t tile = id >> 6;
+  uint32_t in = (uint32_t)(id & 63u);
+  uint32_t x = (uint32_t)(tile % w.tiles_x) * 8u + (in & 7u), y = (uint32_t)(tile / w.tiles_x) * 8u + (in >> 3);
+  if (x >= w.width || y >= w.height) return false;
+  q = (uint64_t)y * w.width + x;
+  return true;
+}
+__device__ __forceinline__ Ray slot_ray(const DPixelMap& pm, const DCamera& cam, uint64_t q) {
+  if (pm.mode == 3) {
+    const double* rr = pm.rays + 6 * q;
+    Ray r;
+    r.ox = rr[0]; r.oy = rr[1]; r.oz = rr[2]; r.dx = rr[3]; r.dy = rr[4]; r.dz = rr[5];
+    return r;
+  }
+  uint64_t i;
+  if (pm.mode == 0) i = pm.first + q;
+  else if (pm.mode == 1) i = pm.indices[q];
+  else i = ((uint64_t)pm.row_first + (q / cam.hsize) * pm.row_step) * cam.hsize + (q % cam.hsize);
+  return camera_ray(cam, i);
+}
+
 }  // namespace
 
-// One lane = one pixel.  COUNT selects the variant that publishes work counters.
-template <bool COUNT>
+// v1/v3: one lane walks one pixel's ray tree at a time (closest pass, shading, shadow passes, pending children).
+// REFILL = false (v1): one pixel per lane, the wave ends with its slowest pixel.
+// REFILL = true  (v3): a lane that finishes its pixel immediately takes the next work id from a global counter and
+//   keeps iterating the same ray loop, so the wave's lanes stay busy until the frame runs out (persistent waves,
+//   refill at ray granularity); the grid is sized to the resident wave count.
+template <bool COUNT, bool REFILL>
 __global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD) rtc_trace_kernel(DScene S, DCamera cam, DPixelMap pm, int fuel0, double* __restrict__ rgb, double* __restrict__ hit_t,
-                                                        int* __restrict__ hit_prim, int* __restrict__ hit_k, DStats* __restrict__ stats) {
+                                                        int* __restrict__ hit_prim, int* __restrict__ hit_k, DStats* __restrict__ stats,
+                                                        unsigned long long* __restrict__ next_work) {
   __shared__ int lds_stack[RTC_BVH_STACK * RTC_BLOCK];
-  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int* stack = lds_stack + threadIdx.x;
   const int stride = RTC_BLOCK;
   Counters C = {0, 0, 0, 0, 0};
   unsigned n_primary = 0, n_shadow = 0, n_reflect = 0, n_refract = 0, n_container = 0;
+  const WorkMap wm = make_workmap(pm, cam);
 
-  if (q < pm.n) {
-    Ray ray;
-    if (pm.mode == 3) {
-      const double* rr = pm.rays + 6 * q;
-      ray.ox = rr[0]; ray.oy = rr[1]; ray.oz = rr[2]; ray.dx = rr[3]; ray.dy = rr[4]; ray.dz = rr[5];
-    } else {
-      uint64_t i;
-      if (pm.mode == 0) i = pm.first + q;
-      else if (pm.mode == 1) i = pm.indices[q];
-      else i = ((uint64_t)pm.row_first + (q / cam.hsize) * pm.row_step) * cam.hsize + (q % cam.hsize);
-      ray = camera_ray(cam, i);
-    }
+  // first work id of this lane, then (REFILL) ids from the counter, which starts at gridDim.x * blockDim.x
+  uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t q = 0;
+  bool have = false;
+  while (id < wm.n_work) {
+    if (work_to_slot(wm, id, q)) { have = true; break; }
+    if (!REFILL) break;
+    id = atomicAdd(next_work, 1ull);
+  }
+
+  if (have) {
+    Ray ray = slot_ray(pm, cam, q);
 
     Pending pend[RTC_MAX_FUEL];
     int np = 0;
@@ -847,14 +897,26 @@ __global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD) rtc_trace_kerne
           }
         }
       }
-      if (np == 0) break;
+      if (np == 0) {
+        rgb[3 * q + 0] = acc_r;
+        rgb[3 * q + 1] = acc_g;
+        rgb[3 * q + 2] = acc_b;
+        if (!REFILL) break;
+        bool more = false;
+        for (;;) {
+          id = atomicAdd(next_work, 1ull);
+          if (id >= wm.n_work) break;
+          if (work_to_slot(wm, id, q)) { more = true; break; }
+        }
+        if (!more) break;
+        ray = slot_ray(pm, cam, q);
+        acc_r = 0.0; acc_g = 0.0; acc_b = 0.0; weight = 1.0; fuel = fuel0; kind = 0; first = true;
+        continue;
+      }
       const Pending& p = pend[--np];
       ray.ox = p.ox; ray.oy = p.oy; ray.oz = p.oz; ray.dx = p.dx; ray.dy = p.dy; ray.dz = p.dz;
       weight = p.weight; fuel = p.fuel; kind = p.kind;
     }
-    rgb[3 * q + 0] = acc_r;
-    rgb[3 * q + 1] = acc_g;
-    rgb[3 * q + 2] = acc_b;
   }
 
   if (COUNT || true) {
@@ -1386,10 +1448,28 @@ void rtc_launch_persist(const DScene& S, const DCamera& cam, const DPixelMap& pm
 
 // ---- host-callable launcher (C++ linkage, used by rtc_scene.cpp) ------------------------------------------
 void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
-                      DStats* stats, bool count, hipStream_t stream) {
+                      DStats* stats, bool count, hipStream_t stream, unsigned refill_blocks, unsigned long long* next_work) {
   if (pm.n == 0) return;
   dim3 block(RTC_BLOCK);
-  dim3 grid((unsigned)((pm.n + RTC_BLOCK - 1) / RTC_BLOCK));
-  if (count) hipLaunchKernelGGL(rtc_trace_kernel<true>, grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats);
-  else hipLaunchKernelGGL(rtc_trace_kernel<false>, grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats);
+  if (refill_blocks) {  // v3: persistent grid; next_work was set to refill_blocks * RTC_BLOCK by the caller
+    dim3 grid(refill_blocks);
+    if (count) hipLaunchKernelGGL((rtc_trace_kernel<true, true>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
+    else hipLaunchKernelGGL((rtc_trace_kernel<false, true>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
+    return;
+  }
+  // v1: one lane per work id (tile padding included)
+  uint64_t n_work = pm.n;
+  if ((pm.mode == 0 || pm.mode == 2) && cam.hsize >= 8 && pm.n % cam.hsize == 0 && (pm.mode == 2 || pm.first % cam.hsize == 0))
+    n_work = (uint64_t)((cam.hsize + 7) / 8) * ((pm.n / cam.hsize + 7) / 8) * 64;
+  dim3 grid((unsigned)((n_work + RTC_BLOCK - 1) / RTC_BLOCK));
+  if (count) hipLaunchKernelGGL((rtc_trace_kernel<true, false>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
+  else hipLaunchKernelGGL((rtc_trace_kernel<false, false>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
 }
+#ifndef RTC_EMU
+int rtc_v3_blocks_per_cu(void) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtc_trace_kernel<false, true>, RTC_BLOCK, 0) != hipSuccess || nb <= 0) nb = 4;
+  return nb;
+}
+#endif
+int rtc_v1_block(void) { return RTC_BLOCK; }

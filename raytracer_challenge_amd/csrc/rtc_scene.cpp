@@ -17,7 +17,9 @@
 #include "scene_build.hpp"
 
 void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
-                      DStats* stats, bool count, hipStream_t stream);
+                      DStats* stats, bool count, hipStream_t stream, unsigned refill_blocks, unsigned long long* next_work);
+int rtc_v3_blocks_per_cu(void);
+int rtc_v1_block(void);
 void rtc_launch_persist(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
                         DStats* stats, bool count, unsigned n_waves, unsigned long long* next_pixel, double* ctx_d, int* ctx_i, hipStream_t stream);
 size_t rtc_v2_ctx_doubles(size_t lanes, int fuel);
@@ -58,7 +60,7 @@ struct rtc_scene {
   double* d_ctx_d = nullptr;
   int* d_ctx_i = nullptr;
   size_t cap_ctx_d = 0, cap_ctx_i = 0;
-  unsigned max_waves = 0;
+  unsigned max_waves = 0, max_blocks_v3 = 0;
   int bvh_depth = 0;
   uint32_t n_bvh_nodes = 0, n_mesh_tris = 0;
 
@@ -105,7 +107,16 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
   HIP_OK(hipMemsetAsync(s->d_stats, 0, sizeof(DStats), s->stream));
   HIP_OK(hipEventRecord(s->ev0, s->stream));
   if (s->kernel_version == 1) {
-    rtc_launch_trace(s->d, cam, pm, fuel, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream);
+    rtc_launch_trace(s->d, cam, pm, fuel, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream, 0, s->d_next);
+  } else if (s->kernel_version == 3) {
+    // persistent v1 with per-lane refill: the work counter starts after the ids the grid's lanes take implicitly
+    unsigned blocks = s->max_blocks_v3;
+    uint64_t need = (pm.n + (uint64_t)rtc_v1_block() - 1) / (uint64_t)rtc_v1_block();
+    if (need < blocks) blocks = (unsigned)need;
+    unsigned long long start = (unsigned long long)blocks * (unsigned long long)rtc_v1_block();
+    HIP_OK(hipMemcpyAsync(s->d_next, &start, sizeof(start), hipMemcpyHostToDevice, s->stream));
+    HIP_OK(hipEventRecord(s->ev0, s->stream));
+    rtc_launch_trace(s->d, cam, pm, fuel, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream, blocks, s->d_next);
   } else {
     const unsigned wave = (unsigned)rtc_v2_wave();
     uint64_t need_waves = (pm.n + wave - 1) / wave;
@@ -233,9 +244,11 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
   HIP_OK(hipMemset(s->d_stats, 0, sizeof(DStats)));
   HIP_OK(hipMalloc((void**)&s->d_next, sizeof(unsigned long long)));
   {
-    // RTC_KERNEL=1 selects the per-pixel kernel (v1) for A/B runs; both are HIP paths.
+    // RTC_KERNEL selects the kernel for A/B runs (all are HIP paths): 1 = one pixel per lane, 2 = persistent state machine
+    // with voted step kinds, 3 (default) = v1 with per-lane refill at ray granularity.
     const char* kv = std::getenv("RTC_KERNEL");
-    s->kernel_version = (kv && kv[0] == '1') ? 1 : 2;
+    s->kernel_version = kv ? std::atoi(kv) : 3;
+    if (s->kernel_version < 1 || s->kernel_version > 3) s->kernel_version = 3;
     // hipDeviceGetAttribute, not hipGetDeviceProperties: the property struct's layout differs between ROCm releases and
     // this library may run on the HIP runtime PyTorch loaded first.
     int n_cu = 0;
@@ -243,6 +256,9 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     int per_cu = rtc_v2_waves_per_cu();
     if (const char* w = std::getenv("RTC_V2_WAVES_PER_CU")) per_cu = std::max(1, std::atoi(w));
     s->max_waves = (unsigned)std::max(1, n_cu * per_cu);
+    int per_cu3 = rtc_v3_blocks_per_cu();
+    if (const char* w = std::getenv("RTC_V3_BLOCKS_PER_CU")) per_cu3 = std::max(1, std::atoi(w));
+    s->max_blocks_v3 = (unsigned)std::max(1, n_cu * per_cu3);
   }
   *out = s.release();
   return RTC_OK;
