@@ -247,12 +247,34 @@ __device__ __forceinline__ int prim_hits(const DScene& S, const DPrim& P, const 
 // the BVH leaf; all other rays are tested in the leaf only.  policy: 0 always, 1 skip if quirk, 2 only if quirk.
 __device__ __forceinline__ void visit_prim(const DScene& S, int prim, const Ray& r, Trav& T, Counters& C, int policy) {
   DPrim P = S.prims[prim];
-  Ray o = to_object(S.xf_inv + 12 * P.xform, r);
-  if (policy != 0) {
+  const double* __restrict__ m = S.xf_inv + 12 * P.xform;
+  if (P.geom == 1) {
+    // Plane (src/shape.rs:621-633) only reads origin.y and direction.y of the object-space ray: evaluate that one row of
+    // Ray::transform, in the same order, and skip the other two.
+    C.analytic_tests++;
+    double oy = m[4] * r.ox + m[5] * r.oy + m[6] * r.oz + m[7] * 1.0;
+    double dy = m[4] * r.dx + m[5] * r.dy + m[6] * r.dz + m[7] * 0.0;
+    if (fabs(dy - 0.0) < EPS) return;
+    double t = -oy / dy;
+    accept(T, C, prim, 1, &t);
+    return;
+  }
+  if (policy == 2) {
+    // quirk scan: the condition needs the object-space DIRECTION only; most candidates are rejected here
+    double dx = m[0] * r.dx + m[1] * r.dy + m[2] * r.dz + m[3] * 0.0;
+    double dy = m[4] * r.dx + m[5] * r.dy + m[6] * r.dz + m[7] * 0.0;
+    double dz = m[8] * r.dx + m[9] * r.dy + m[10] * r.dz + m[11] * 0.0;
+    bool quirk = false;
+    if (P.geom == 2) quirk = fabs(dx) < EPS || fabs(dy) < EPS || fabs(dz) < EPS;
+    else if (P.geom == 4) quirk = fabs((dx * dx - dy * dy + dz * dz) - 0.0) < EPS;
+    if (!quirk) return;
+  }
+  Ray o = to_object(m, r);
+  if (policy == 1) {
     bool quirk = false;
     if (P.geom == 2) quirk = fabs(o.dx) < EPS || fabs(o.dy) < EPS || fabs(o.dz) < EPS;
     else if (P.geom == 4) quirk = fabs((o.dx * o.dx - o.dy * o.dy + o.dz * o.dz) - 0.0) < EPS;
-    if (quirk != (policy == 2)) return;
+    if (quirk) return;
   }
   double t[4], u = 0.0, v = 0.0;
   if (P.geom >= 5) C.tri_tests++; else C.analytic_tests++;

@@ -100,7 +100,7 @@ struct ProgramBuilder {
   int32_t build_quirk_grid(int32_t q0, int32_t qn) {
     int bands = 0;
     for (int32_t i = 0; i < qn; i++) bands += D.prims[quirk_prim[q0 + i]].geometry == RTC_CUBE ? 3 : 1;
-    int n = std::min(256, std::max(8, (int)std::ceil(0.14 * bands)));
+    int n = std::min(256, std::max(8, (int)std::ceil(0.6 * bands)));  // ~1.1 * bands / n candidates per cell
     DQuirkGrid g{n, (int32_t)qcell.size(), q0, qn};
     const double eps = 0.00001, lmin = RTC_QGRID_MIN_LEN;
     struct Rows { double r[3][3], len[3]; bool cube; int32_t prim; };
