@@ -22,7 +22,8 @@ struct Builder {
   uint32_t base;                 // global offset of this BVH's first packed item
   int max_depth = 0;
   bool median_only = false;  // fallback when SAH produced a tree deeper than the traversal stack
-  static constexpr int kLeaf = 4, kBins = 16;
+  static constexpr int kBins = 16;
+  int kLeaf = 4;  // max items per leaf (<= 8: 3 bits in the leaf ref)
 
   struct Range { double lo[3], hi[3]; };
   static void grow(Range& r, const Item& it) {
@@ -156,9 +157,11 @@ struct Builder {
 };
 
 // Returns the root node index (always an inner node, so traversal can start from a node).
-inline int32_t build(const std::vector<Item>& items, std::vector<DBvhNode>& nodes, std::vector<uint32_t>& order, uint32_t base, int* depth, bool median_only = false) {
+inline int32_t build(const std::vector<Item>& items, std::vector<DBvhNode>& nodes, std::vector<uint32_t>& order, uint32_t base, int* depth, bool median_only = false,
+                     int leaf_max = 4) {
   Builder B{items, nodes, order, base};
   B.median_only = median_only;
+  B.kLeaf = leaf_max < 1 ? 1 : (leaf_max > 8 ? 8 : leaf_max);
   std::vector<uint32_t> ids(items.size());
   for (uint32_t i = 0; i < ids.size(); i++) ids[i] = i;
   Builder::Range r;

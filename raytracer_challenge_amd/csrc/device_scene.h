@@ -110,7 +110,8 @@ struct DStats {  // device-side counters (atomically accumulated per wave)
   unsigned long long accel_nodes, group_tests, tri_tests, analytic_tests, nan_ts;
   unsigned long long guard;  // bit mask of tripped traversal guards (0 = none)
   unsigned long long guard_claim;  // first tripping lane claims the info slots
-  long long guard_info[8];   // code, it_kind, it, it_end, value, cur, pc, mode of the first trip
+  long long guard_info[8];
+  unsigned long long diag[32];  // RTC_DIAG builds only: region cycles / lane-utilisation sums (scripts/diag_report.py)   // code, it_kind, it, it_end, value, cur, pc, mode of the first trip
 };
 
 #define RTC_MAX_FUEL 16

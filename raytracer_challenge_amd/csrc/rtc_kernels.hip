@@ -60,6 +60,20 @@ struct Counters {
   unsigned int accel_nodes, group_tests, tri_tests, analytic_tests, nan_ts;
 };
 
+// ---- diagnostics (RTC_DIAG builds only; the shipped kernel compiles these to nothing) ----------------------------------
+// diag[2r] += cycles a lane spent in region r (every participating lane measures the wave's wall time of the region),
+// diag[2r+1] += 1 per participation; diag[16+2j] += active lanes, diag[16+2j+1] += 1 per executed iteration of loop j.
+#ifdef RTC_DIAG
+__device__ unsigned long long* g_diag = nullptr;
+#define DIAG_T0() diag_t0_ = __builtin_amdgcn_s_memtime()
+#define DIAG_REGION(r) do { unsigned long long t1_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_diag[2 * (r)], t1_ - diag_t0_); atomicAdd(&g_diag[2 * (r) + 1], 1ull); diag_t0_ = t1_; } while (0)
+#define DIAG_LOOP(j) do { unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) { atomicAdd(&g_diag[16 + 2 * (j)], (unsigned long long)__popcll(m_)); atomicAdd(&g_diag[16 + 2 * (j) + 1], 1ull); } } while (0)
+#else
+#define DIAG_T0() do {} while (0)
+#define DIAG_REGION(r) do {} while (0)
+#define DIAG_LOOP(j) do {} while (0)
+#endif
+
 // Rust f64::max/min: a NaN operand is ignored.
 __device__ __forceinline__ double rmax(double a, double b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
 __device__ __forceinline__ double rmin(double a, double b) { return (a != a) ? b : ((b != b) ? a : (a < b ? a : b)); }
@@ -325,7 +339,9 @@ __device__ __forceinline__ void bvh_walk(const DScene& S, int root, const Ray& w
   int sp = 0;
   int cur = root;
   for (;;) {
+    DIAG_LOOP(0);
     if (cur >= 0) {
+      DIAG_LOOP(3);
       const DBvhNode* N = S.bvh + cur;
       C.accel_nodes++;
       double slack = 1e-7 * fmax(fabs(T.thi), 1.0);
@@ -345,6 +361,7 @@ __device__ __forceinline__ void bvh_walk(const DScene& S, int root, const Ray& w
     } else {
       int first = (~cur) >> 3, cnt = ((~cur) & 7) + 1;
       for (int i = first; i < first + cnt; i++) {
+        DIAG_LOOP(1);
         if (MESH) {
           double t, u, v;
           C.tri_tests++;
@@ -366,6 +383,7 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
   int pc = 0;
   const int n = S.n_ops;
   while (pc < n) {
+    DIAG_LOOP(2);
     DOp op = S.ops[pc];
     if (op.op == OP_PRIM) {
       visit_prim(S, op.a, r, T, C, 0);
@@ -774,6 +792,11 @@ __global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD) rtc_trace_kerne
   Counters C = {0, 0, 0, 0, 0};
   unsigned n_primary = 0, n_shadow = 0, n_reflect = 0, n_refract = 0, n_container = 0;
   const WorkMap wm = make_workmap(pm, cam);
+#ifdef RTC_DIAG
+  g_diag = stats->diag;
+  unsigned long long diag_t0_ = 0;
+  const unsigned long long diag_k0 = __builtin_amdgcn_s_memtime();
+#endif
 
   // first work id of this lane, then (REFILL) ids from the counter, which starts at gridDim.x * blockDim.x
   uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -799,9 +822,12 @@ __global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD) rtc_trace_kerne
 
     for (;;) {
       if (kind == 0) n_primary++; else if (kind == 1) n_reflect++; else n_refract++;
+      DIAG_LOOP(4);
+      DIAG_T0();
       Trav T;
       reset_closest(T, MODE_CLOSEST);
       traverse(S, ray, T, C, stack, stride);
+      DIAG_REGION(0);
       bool did_hit = T.best_prim != 0x7fffffff;
       if (first) {
         first = false;
@@ -831,6 +857,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD) rtc_trace_kerne
           traverse(S, ray, K, C, stack, stride);
           if (K.c1_prim >= 0) n1 = S.mat[8 * S.prims[K.c1_prim].mat + 6];
           if (K.c2_prim >= 0) n2 = S.mat[8 * S.prims[K.c2_prim].mat + 6];
+          DIAG_REGION(1);
         }
 
         // Pattern::color_at(material_inv * over_point) — identical for every light (src/shape.rs:437)
@@ -846,9 +873,11 @@ __global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD) rtc_trace_kerne
           else pattern_color(S, S.mat_pattern[P.mat], x, y, z, w, cr, cg, cb);
         }
 
+        DIAG_REGION(2);
         // World::shade_hit (src/world.rs:50-82): per light, shadow test + Phong (src/shape.rs:429-462)
         double sr = 0.0, sg = 0.0, sb = 0.0;
         for (int l = 0; l < S.n_lights; l++) {
+          DIAG_LOOP(5);
           const double* LG = S.lights + 6 * l;
           double vx = LG[3] - st.px, vy = LG[4] - st.py, vz = LG[5] - st.pz;
           double distance = sqrt(vx * vx + vy * vy + vz * vz);
@@ -859,7 +888,9 @@ __global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD) rtc_trace_kerne
           Trav Sh;
           reset_closest(Sh, S.all_cast_shadow ? MODE_SHADOW_ANY : MODE_SHADOW_CLOSEST);
           if (S.all_cast_shadow) Sh.thi = distance;
+          DIAG_T0();
           traverse(S, sray, Sh, C, stack, stride);
+          DIAG_REGION(3);
           bool shadowed;
           if (S.all_cast_shadow) shadowed = Sh.shadowed != 0;
           else shadowed = (Sh.best_prim != 0x7fffffff) && (S.prims[Sh.best_prim].flags & 1u) && (Sh.best_t < distance);
@@ -884,6 +915,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD) rtc_trace_kerne
           sr += (lr + dr) + pr; sg += (lg + dg) + pg; sb += (lb + db) + pb;
         }
         acc_r += weight * sr; acc_g += weight * sg; acc_b += weight * sb;
+        DIAG_T0();
 
         // reflected_color / refracted_color (src/world.rs:84-132), once per light in the reference -> factor L
         if (fuel > 0) {
@@ -919,6 +951,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD) rtc_trace_kerne
           }
         }
       }
+      DIAG_REGION(5);
       if (np == 0) {
         rgb[3 * q + 0] = acc_r;
         rgb[3 * q + 1] = acc_g;
@@ -941,6 +974,10 @@ __global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD) rtc_trace_kerne
     }
   }
 
+#ifdef RTC_DIAG
+  atomicAdd(&g_diag[14], __builtin_amdgcn_s_memtime() - diag_k0);
+  atomicAdd(&g_diag[15], 1ull);
+#endif
   if (COUNT || true) {
     // nan_ts must always be published (error reporting); the rest only in the counting variant
     if (C.nan_ts) atomicAdd(&stats->nan_ts, (unsigned long long)C.nan_ts);

@@ -158,6 +158,11 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
     stats->kernel_ms = ms;
     stats->n_launches = 1;
   }
+  if (std::getenv("RTC_DIAG_DUMP")) {  // RTC_DIAG builds: raw region / utilisation counters for scripts/diag_report.py
+    std::fprintf(stderr, "[rtc-diag]");
+    for (int i = 0; i < 32; i++) std::fprintf(stderr, " %llu", (unsigned long long)h.diag[i]);
+    std::fprintf(stderr, "\n");
+  }
   if (h.guard) {
     std::string info;
     for (int i = 0; i < 8; i++) info += " " + std::to_string(h.guard_info[i]);
@@ -244,11 +249,11 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
   HIP_OK(hipMemset(s->d_stats, 0, sizeof(DStats)));
   HIP_OK(hipMalloc((void**)&s->d_next, sizeof(unsigned long long)));
   {
-    // RTC_KERNEL selects the kernel for A/B runs (all are HIP paths): 1 = one pixel per lane, 2 = persistent state machine
-    // with voted step kinds, 3 (default) = v1 with per-lane refill at ray granularity.
+    // RTC_KERNEL selects the kernel for A/B runs (all are HIP paths): 1 (default, fastest measured) = one pixel per lane, 8x8 tiles;
+    // 2 = persistent state machine with voted step kinds; 3 = v1 with per-lane refill at ray granularity.
     const char* kv = std::getenv("RTC_KERNEL");
-    s->kernel_version = kv ? std::atoi(kv) : 3;
-    if (s->kernel_version < 1 || s->kernel_version > 3) s->kernel_version = 3;
+    s->kernel_version = kv ? std::atoi(kv) : 1;
+    if (s->kernel_version < 1 || s->kernel_version > 3) s->kernel_version = 1;
     // hipDeviceGetAttribute, not hipGetDeviceProperties: the property struct's layout differs between ROCm releases and
     // this library may run on the HIP runtime PyTorch loaded first.
     int n_cu = 0;

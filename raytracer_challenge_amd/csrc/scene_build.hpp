@@ -4,6 +4,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -162,14 +163,20 @@ struct ProgramBuilder {
     return (int32_t)qgrids.size() - 1;
   }
 
-  int32_t build_tree(const std::vector<bvh::Item>& items, std::vector<uint32_t>& order, uint32_t base) {
+  // Leaf sizes: an analytic primitive test (own matrix, geometry switch) is ~3x an inner node and runs at poor lane
+  // utilisation, so analytic leaves hold one primitive; packed triangles are cheap and uniform, so mesh leaves hold four.
+  static int leaf_size(bool mesh) {
+    const char* e = std::getenv(mesh ? "RTC_LEAF_MESH" : "RTC_LEAF_ANALYTIC");
+    return e ? std::atoi(e) : (mesh ? 4 : 1);
+  }
+  int32_t build_tree(const std::vector<bvh::Item>& items, std::vector<uint32_t>& order, uint32_t base, bool mesh) {
     int depth = 0;
     size_t n0 = bvh_nodes.size(), o0 = order.size();
-    int32_t root = bvh::build(items, bvh_nodes, order, base, &depth);
+    int32_t root = bvh::build(items, bvh_nodes, order, base, &depth, false, leaf_size(mesh));
     if (depth > RTC_BVH_STACK - 2) {
       bvh_nodes.resize(n0);
       order.resize(o0);
-      root = bvh::build(items, bvh_nodes, order, base, &depth, true);
+      root = bvh::build(items, bvh_nodes, order, base, &depth, true, leaf_size(mesh));
     }
     max_depth = std::max(max_depth, depth);
     return root;
@@ -202,7 +209,7 @@ struct ProgramBuilder {
       if (items.size() < kMinAccel) { for (int32_t pi : ids) rest.push_back(pi); continue; }
       std::vector<uint32_t> order;
       uint32_t base = (uint32_t)mtri_prim.size();
-      int32_t root = build_tree(items, order, base);
+      int32_t root = build_tree(items, order, base, true);
       for (uint32_t k : order) {
         int32_t pi = ids[k];
         const double* g = D.tri_p1e1e2 + 9 * (size_t)D.prims[pi].data;
@@ -225,7 +232,7 @@ struct ProgramBuilder {
       if (!items.empty()) {
         std::vector<uint32_t> order;
         uint32_t base = (uint32_t)item_prim.size();
-        int32_t root = build_tree(items, order, base);
+        int32_t root = build_tree(items, order, base, false);
         for (uint32_t k : order) item_prim.push_back(ids[k]);
         ops.push_back({OP_BVH, root, 0, (int32_t)items.size()});
         int32_t q0 = (int32_t)quirk_prim.size();

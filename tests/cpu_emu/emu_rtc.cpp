@@ -31,10 +31,10 @@ static int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double*
   DStats st;
   std::memset(&st, 0, sizeof(st));
   const char* kv = std::getenv("RTC_KERNEL");
-  if (kv && kv[0] == '1') {
+  if (!kv || kv[0] == '1') {
     unsigned long long next = 0;
     rtc_launch_trace(s->d, cam, pm, fuel, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr, 0, &next);
-  } else if (!kv || kv[0] == '3') {  // v1 with per-lane refill, a small persistent grid
+  } else if (kv[0] == '3') {  // v1 with per-lane refill, a small persistent grid
     unsigned blocks = (unsigned)std::min<uint64_t>((pm.n + rtc_v1_block() - 1) / rtc_v1_block(), 3);
     unsigned long long next = (unsigned long long)blocks * rtc_v1_block();
     rtc_launch_trace(s->d, cam, pm, fuel, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr, blocks, &next);

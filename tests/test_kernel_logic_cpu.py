@@ -31,6 +31,28 @@ def test_emulated_kernel_matches_oracle(emu, orc, name):
     assert_parity(emu, orc, world, cam, 5, label=name)
 
 
+@pytest.mark.parametrize("version", ["2", "3"])
+def test_emulated_other_kernel_versions(emu, orc, version, monkeypatch):
+    """The persistent kernels (v2 voted state machine, v3 per-lane refill) through the same emulator (one-lane waves)."""
+    monkeypatch.setenv("RTC_KERNEL", version)
+    for name in ("synthetic_cones_grouped", "teapot_low", "nested_glass", "cube_lattice", "synthetic_mesh_small"):
+        cam, world = cases.SMALL_CASES[name]()
+        assert_parity(emu, orc, world, cam, 5, label="kernel v%s %s" % (version, name))
+
+
+def test_simt_emulation_of_voted_kernel(orc, monkeypatch):
+    """v2 with 8-lane waves, one thread per lane, ballots through a barrier: exercises votes, refill and suspended lanes."""
+    import subprocess
+    from emu_lib import EMU_DIR
+    from raytracer_challenge_amd.backend import Backend
+    subprocess.run(["make", "-s", "-C", EMU_DIR, "simt"], check=True)
+    monkeypatch.setenv("RTC_KERNEL", "2")
+    simt = Backend(os.path.join(EMU_DIR, "_build", "librtc_emu_simt.so"))
+    for name in ("teapot_low", "nested_glass"):
+        cam, world = cases.SMALL_CASES[name]()
+        assert_parity(simt, orc, world, cam, 5, label="simt " + name)
+
+
 @pytest.mark.parametrize("fuel", [0, 1, 8])
 def test_emulated_kernel_fuel(emu, orc, fuel):
     cam, world = cases.nested_glass()

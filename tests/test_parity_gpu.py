@@ -21,6 +21,16 @@ def test_hip_matches_oracle(hip, orc, name):
     assert_parity(hip, orc, world, cam, 5, label=name)
 
 
+@pytest.mark.parametrize("version", ["1", "2", "3"])
+def test_hip_every_kernel_version(hip, orc, version, monkeypatch):
+    """RTC_KERNEL selects the kernel at scene creation: 1 = pixel per lane (default), 2 = persistent voted state machine,
+    3 = per-lane refill.  All three must be bit-exact in hits on analytic, mesh, grouped and glass scenes."""
+    monkeypatch.setenv("RTC_KERNEL", version)
+    for name in ("synthetic_cones_grouped", "teapot_low", "nested_glass", "cube_lattice", "synthetic_mesh_small", "patterns_and_noise"):
+        cam, world = cases.SMALL_CASES[name]()
+        assert_parity(hip, orc, world, cam, 5, label="kernel v%s %s" % (version, name))
+
+
 @pytest.mark.parametrize("fuel", [0, 1, 8])
 def test_hip_fuel(hip, orc, fuel):
     cam, world = cases.nested_glass()
