@@ -92,9 +92,9 @@ struct DScene {
 // Which pixels a launch covers.
 struct DPixelMap {
   uint64_t n;                 // pixels in this launch
-  uint64_t first;             // mode 0: i = first + q
+  uint64_t first;             // unused on device (a contiguous range is issued as mode 2, step 1, or as mode 1)
   const uint64_t* indices;    // mode 1: i = indices[q]
-  uint32_t mode;              // 0 range, 1 list, 2 interleaved rows, 3 explicit rays
+  uint32_t mode;              // 1 list, 2 interleaved rows, 3 explicit rays
   uint32_t row_first, row_step;  // mode 2: row = row_first + (q / hsize) * row_step, x = q % hsize
   const double* rays;         // mode 3: n x {o, d}
 };

@@ -742,7 +742,7 @@ struct WorkMap {
 __device__ __forceinline__ WorkMap make_workmap(const DPixelMap& pm, const DCamera& cam) {
   WorkMap w;
   w.tiled = 0; w.tiles_x = 0; w.width = 0; w.height = 0; w.n_work = pm.n;
-  if ((pm.mode == 0 || pm.mode == 2) && cam.hsize >= 8 && pm.n % cam.hsize == 0 && (pm.mode == 2 || pm.first % cam.hsize == 0)) {
+  if (pm.mode == 2 && cam.hsize >= 8 && pm.n % cam.hsize == 0) {
     w.tiled = 1;
     w.width = (uint32_t)cam.hsize;
     w.height = (uint32_t)(pm.n / cam.hsize);
@@ -768,9 +768,9 @@ __device__ __forceinline__ Ray slot_ray(const DPixelMap& pm, const DCamera& cam,
     r.ox = rr[0]; r.oy = rr[1]; r.oz = rr[2]; r.dx = rr[3]; r.dy = rr[4]; r.dz = rr[5];
     return r;
   }
+  // the host only issues modes 1 (index list), 2 (interleaved rows; a contiguous whole-row range is step 1) and 3 (rays)
   uint64_t i;
-  if (pm.mode == 0) i = pm.first + q;
-  else if (pm.mode == 1) i = pm.indices[q];
+  if (pm.mode == 1) i = pm.indices[q];
   else i = ((uint64_t)pm.row_first + (q / cam.hsize) * pm.row_step) * cam.hsize + (q % cam.hsize);
   return camera_ray(cam, i);
 }
@@ -1235,8 +1235,7 @@ __global__ void __launch_bounds__(RTC_WAVE, RTC_V2_WAVES_PER_SIMD) rtc_persist_k
             L.r.ox = rr[0]; L.r.oy = rr[1]; L.r.oz = rr[2]; L.r.dx = rr[3]; L.r.dy = rr[4]; L.r.dz = rr[5];
           } else {
             uint64_t i;
-            if (pm.mode == 0) i = pm.first + mine;
-            else if (pm.mode == 1) i = pm.indices[mine];
+            if (pm.mode == 1) i = pm.indices[mine];
             else i = ((uint64_t)pm.row_first + (mine / cam.hsize) * pm.row_step) * cam.hsize + (mine % cam.hsize);
             L.r = camera_ray(cam, i);
           }
@@ -1518,7 +1517,7 @@ void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, 
   }
   // v1: one lane per work id (tile padding included)
   uint64_t n_work = pm.n;
-  if ((pm.mode == 0 || pm.mode == 2) && cam.hsize >= 8 && pm.n % cam.hsize == 0 && (pm.mode == 2 || pm.first % cam.hsize == 0))
+  if (pm.mode == 2 && cam.hsize >= 8 && pm.n % cam.hsize == 0)
     n_work = (uint64_t)((cam.hsize + 7) / 8) * ((pm.n / cam.hsize + 7) / 8) * 64;
   dim3 grid((unsigned)((n_work + RTC_BLOCK - 1) / RTC_BLOCK));
   if (count) hipLaunchKernelGGL((rtc_trace_kernel<true, false>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);

@@ -299,8 +299,20 @@ int rtc_render(rtc_scene* s, const rtc_camera* cam, int32_t fuel, const uint64_t
   HIP_OK(hipSetDevice(s->device));
   int rc = ensure_px(s, n, hits != nullptr);
   if (rc != RTC_OK) return rc;
+  // A contiguous range is expressed through the two pixel maps the kernels are validated with on hardware: whole rows ->
+  // interleaved-row map with step 1; anything else -> an explicit index list.
   DPixelMap pm{};
-  pm.n = n; pm.first = first; pm.mode = 0;
+  pm.n = n;
+  std::vector<uint64_t> range_idx;
+  if (!pixel_indices) {
+    if (first % cam->hsize == 0 && n % cam->hsize == 0) {
+      pm.mode = 2; pm.row_first = (uint32_t)(first / cam->hsize); pm.row_step = 1;
+    } else {
+      range_idx.resize(n);
+      for (uint64_t i = 0; i < n; i++) range_idx[i] = first + i;
+      pixel_indices = range_idx.data();
+    }
+  }
   if (pixel_indices) {
     for (uint64_t i = 0; i < n; i++)
       if (pixel_indices[i] >= total) return rtc_fail(RTC_ERR_INVALID, "pixel index exceeds the image");
@@ -310,7 +322,7 @@ int rtc_render(rtc_scene* s, const rtc_camera* cam, int32_t fuel, const uint64_t
       HIP_OK(hipMalloc((void**)&s->d_idx, n * sizeof(uint64_t)));
       s->cap_idx = n;
     }
-    HIP_OK(hipMemcpyAsync(s->d_idx, pixel_indices, n * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
+    HIP_OK(hipMemcpy(s->d_idx, pixel_indices, n * sizeof(uint64_t), hipMemcpyHostToDevice));
     pm.mode = 1; pm.indices = s->d_idx;
   }
   DCamera dc;

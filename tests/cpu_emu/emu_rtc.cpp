@@ -79,7 +79,13 @@ void rtc_scene_destroy(rtc_scene* s) { delete s; }
 uint64_t rtc_scene_device_bytes(const rtc_scene*) { return 0; }
 int rtc_render(rtc_scene* s, const rtc_camera* cam, int32_t fuel, const uint64_t* idx, uint64_t first, uint64_t n, double* rgb, rtc_hit* hits, rtc_stats* stats) {
   DPixelMap pm{};
-  pm.n = n; pm.first = first; pm.mode = idx ? 1 : 0; pm.indices = idx;
+  pm.n = n;
+  std::vector<uint64_t> range_idx;
+  if (!idx) {
+    if (first % cam->hsize == 0 && n % cam->hsize == 0) { pm.mode = 2; pm.row_first = (uint32_t)(first / cam->hsize); pm.row_step = 1; }
+    else { range_idx.resize(n); for (uint64_t i = 0; i < n; i++) range_idx[i] = first + i; idx = range_idx.data(); }
+  }
+  if (idx) { pm.mode = 1; pm.indices = idx; }
   DCamera dc;
   to_dcam(*cam, &dc);
   return run(s, dc, pm, fuel, rgb, hits, stats);
