@@ -46,6 +46,15 @@ def make_workload(name):
     return cam, world, desc
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch measured with rocprofv3 PMC passes for this workload (profiles/pmc_traffic.json), or None."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[workload]
+        return t["fetch_bytes"] + t["write_bytes"], t["source"]
+    except Exception:
+        return None, None
+
+
 def cpu_threads():
     """Threads this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box hands one GPU a
     16-core share of a 256-thread host)."""
@@ -169,7 +178,8 @@ def main():
             "config": {"workload": desc, "hsize": H, "vsize": V, "fuel": args.fuel, "lights": nw.n_lights, "primitives": nw.primitive_count,
                        "partition": "rows interleaved by rank, RCCL gather to rank 0" if world_size > 1 else "single GPU",
                        "unique_rays_per_frame": rays_total, "rays_per_pixel": rays_total / (H * V)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(args.workload)[0] if world_size == 1 else None, "traffic_source": pmc_traffic(args.workload)[1],
                          "kernel": "rtc_trace_kernel", "kernel_ms_avg": avg_kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "counters_rank0": {k: cst[k] for k in ("pixels", "unique_rays", "accel_nodes", "group_tests", "tri_tests", "analytic_tests", "rays_container")},
                          "note": "scene (%d B) is L2/Infinity-Cache resident; real HBM traffic ~ framebuffer only (SURVEY.md §8d)" % dr.info()["scene_device_bytes"]},

@@ -9,7 +9,7 @@ from collections import defaultdict
 
 out = sys.argv[1]
 print("# profile summary for", out)
-for f in glob.glob(os.path.join(out, "trace", "*", "*kernel_stats.csv")):
+for f in sorted(glob.glob(os.path.join(out, "trace", "*", "*kernel_stats.csv")), key=os.path.getmtime)[-1:]:
     print("\n## rocprofv3 --kernel-trace --stats (kernel_stats.csv)")
     print(open(f).read().strip())
 log = os.path.join(out, "trace.log")
@@ -23,11 +23,11 @@ print("\n## PMC passes (per-dispatch mean over rtc_trace_kernel<false> dispatche
 for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     if not os.path.isdir(d):
         continue
-    for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+    for f in sorted(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)[-1:]:
         acc, n = defaultdict(float), defaultdict(int)
         for row in csv.DictReader(open(f)):
             kn = row.get("Kernel_Name", "")
-            if "rtc_trace_kernel<false>" not in kn and "rtc_persist_kernel<false>" not in kn:
+            if "rtc_trace_kernel<false" not in kn and "rtc_persist_kernel<false" not in kn:
                 continue
             acc[row["Counter_Name"]] += float(row["Counter_Value"])
             n[row["Counter_Name"]] += 1
