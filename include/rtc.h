@@ -166,6 +166,17 @@ int rtc_render_rows_device(rtc_scene*, const rtc_camera*, int32_t fuel, uint32_t
 /* World::color_at(ray, fuel) for n rays {ox,oy,oz,dx,dy,dz} (host arrays). */
 int rtc_trace_rays(rtc_scene*, const double* rays, uint64_t n, int32_t fuel, double* rgb, rtc_hit* hits, rtc_stats* stats);
 
+/* ---- the step after the path: Color::clamp and Image::ppm ---------------------------------
+ * Color::clamp (src/color.rs:42-46): u8 = round(min(max(c, 0), 1) * 255), round half away from zero, NaN -> 255 (Rust's
+ * f64::min returns the non-NaN operand).  n_values = 3 * pixels.  Device pointers, on the scene's stream. */
+int rtc_quantize_device(rtc_scene*, const double* rgb_dev, uint64_t n_values, uint8_t* out_dev, int sync);
+/* Same through host buffers (upload, quantise on device, download). */
+int rtc_quantize(rtc_scene*, const double* rgb, uint64_t n_values, uint8_t* out);
+/* Image::ppm (src/image.rs:93-112) from quantised pixels: "P3\n{w} {h}\n255", <= 5 pixels per line, a new line at each
+ * row start, trailing newline.  Host-only formatting (no device needed).  Returns the byte count (excluding the NUL);
+ * writes only if cap is large enough. */
+uint64_t rtc_ppm(uint64_t hsize, uint64_t vsize, const uint8_t* rgb8, char* out, uint64_t cap);
+
 /* Blocks until the scene's stream is idle. */
 int rtc_scene_sync(rtc_scene*);
 

@@ -1505,6 +1505,25 @@ void rtc_launch_persist(const DScene& S, const DCamera& cam, const DPixelMap& pm
 }
 
 // ---- host-callable launcher (C++ linkage, used by rtc_scene.cpp) ------------------------------------------
+// Color::clamp (src/color.rs:42-46) over a flat array of channel values.
+__global__ void __launch_bounds__(256) rtc_quantize_kernel(const double* __restrict__ rgb, unsigned char* __restrict__ out, unsigned long long n) {
+  unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    double x = rgb[i];
+    double c = (x != x) ? 1.0 : (x < 1.0 ? x : 1.0);  // x.min(1.0): NaN -> 1.0
+    c = c > 0.0 ? c : 0.0;                            // .max(0.0)
+    double r = round(c * 255.0);                      // half away from zero
+    out[i] = (unsigned char)(r <= 0.0 ? 0.0 : (r >= 255.0 ? 255.0 : r));
+  }
+}
+void rtc_launch_quantize(const double* rgb, unsigned char* out, unsigned long long n, hipStream_t stream) {
+  if (n == 0) return;
+  unsigned long long blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(rtc_quantize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, rgb, out, n);
+}
+
 void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
                       DStats* stats, bool count, hipStream_t stream, unsigned refill_blocks, unsigned long long* next_work) {
   if (pm.n == 0) return;

@@ -19,6 +19,7 @@
 void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
                       DStats* stats, bool count, hipStream_t stream, unsigned refill_blocks, unsigned long long* next_work);
 int rtc_v3_blocks_per_cu(void);
+void rtc_launch_quantize(const double* rgb, unsigned char* out, unsigned long long n, hipStream_t stream);
 int rtc_v1_block(void);
 void rtc_launch_persist(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
                         DStats* stats, bool count, unsigned n_waves, unsigned long long* next_pixel, double* ctx_d, int* ctx_i, hipStream_t stream);
@@ -384,6 +385,58 @@ int rtc_trace_rays(rtc_scene* s, const double* rays, uint64_t n, int32_t fuel, d
     for (uint64_t i = 0; i < n; i++) hits[i] = {t[i], p[i], k[i]};
   }
   return RTC_OK;
+}
+
+int rtc_quantize_device(rtc_scene* s, const double* rgb_dev, uint64_t n_values, uint8_t* out_dev, int sync) {
+  if (!s || (n_values && (!rgb_dev || !out_dev))) return rtc_fail(RTC_ERR_INVALID, "NULL argument");
+  HIP_OK(hipSetDevice(s->device));
+  rtc_launch_quantize(rgb_dev, out_dev, n_values, s->stream);
+  HIP_OK(hipGetLastError());
+  if (sync) HIP_OK(hipStreamSynchronize(s->stream));
+  return RTC_OK;
+}
+
+int rtc_quantize(rtc_scene* s, const double* rgb, uint64_t n_values, uint8_t* out) {
+  if (!s || (n_values && (!rgb || !out))) return rtc_fail(RTC_ERR_INVALID, "NULL argument");
+  if (n_values == 0) return RTC_OK;
+  HIP_OK(hipSetDevice(s->device));
+  double* d_in = nullptr;
+  uint8_t* d_out = nullptr;
+  HIP_OK(hipMalloc((void**)&d_in, n_values * sizeof(double)));
+  if (hipMalloc((void**)&d_out, n_values) != hipSuccess) { (void)hipFree(d_in); return rtc_fail(RTC_ERR_DEVICE, "hipMalloc failed"); }
+  int rc = RTC_OK;
+  if (hipMemcpy(d_in, rgb, n_values * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = rtc_fail(RTC_ERR_DEVICE, "H2D copy failed");
+  if (rc == RTC_OK) rc = rtc_quantize_device(s, d_in, n_values, d_out, 1);
+  if (rc == RTC_OK && hipMemcpy(out, d_out, n_values, hipMemcpyDeviceToHost) != hipSuccess) rc = rtc_fail(RTC_ERR_DEVICE, "D2H copy failed");
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  return rc;
+}
+
+uint64_t rtc_ppm(uint64_t hsize, uint64_t vsize, const uint8_t* rgb8, char* out, uint64_t cap) {
+  // two passes: size, then fill (src/image.rs:93-112)
+  auto digits = [](unsigned v) { return v >= 100 ? 3u : (v >= 10 ? 2u : 1u); };
+  std::string head = "P3\n" + std::to_string(hsize) + " " + std::to_string(vsize) + "\n255";
+  uint64_t size = head.size() + 1;  // + trailing newline
+  const uint64_t n = hsize * vsize;
+  for (uint64_t i = 0; i < n; i++) size += 1 + digits(rgb8[3 * i]) + 1 + digits(rgb8[3 * i + 1]) + 1 + digits(rgb8[3 * i + 2]);
+  if (!out || cap < size + 1) return size;
+  char* p = out;
+  std::memcpy(p, head.data(), head.size());
+  p += head.size();
+  auto put = [&](unsigned v) {
+    if (v >= 100) *p++ = (char)('0' + v / 100);
+    if (v >= 10) *p++ = (char)('0' + (v / 10) % 10);
+    *p++ = (char)('0' + v % 10);
+  };
+  uint64_t j = 0;
+  for (uint64_t i = 0; i < n; i++) {
+    if (i % hsize == 0 || j % 5 == 0) { *p++ = '\n'; j = 1; } else { *p++ = ' '; j += 1; }
+    put(rgb8[3 * i]); *p++ = ' '; put(rgb8[3 * i + 1]); *p++ = ' '; put(rgb8[3 * i + 2]);
+  }
+  *p++ = '\n';
+  *p = 0;
+  return (uint64_t)(p - out);
 }
 
 int rtc_scene_sync(rtc_scene* s) {

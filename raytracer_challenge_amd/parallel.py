@@ -27,13 +27,20 @@ class FrameGatherer:
         import torch
         self.hsize, self.vsize, self.rank, self.world_size, self.dist = hsize, vsize, rank, world_size, dist
         self.n_rows = len(rows_of(rank, world_size, vsize))
-        self.tile = torch.zeros(max_rows(world_size, vsize) * hsize * 3, dtype=torch.float64, device=device)
+        self.max_rows = max_rows(world_size, vsize)
+        self.tile = torch.zeros(self.max_rows * hsize * 3, dtype=torch.float64, device=device)
         self.gathered: Optional[List] = None
         self.image = None
         if rank == 0:
-            self.image = torch.zeros((vsize, hsize, 3), dtype=torch.float64, device=device)
             if world_size > 1:
-                self.gathered = [torch.zeros_like(self.tile) for _ in range(world_size)]
+                # one slab [rank][row j of that rank][x][rgb]; gather_list entries are views of it, so the de-interleave is ONE copy
+                self.slab = torch.zeros((world_size, self.max_rows, hsize, 3), dtype=torch.float64, device=device)
+                self.gathered = [self.slab[r].view(-1) for r in range(world_size)]
+                # image row r + N*j  <-  slab[r, j]: a padded (max_rows*N)-row frame viewed as [j][r]
+                self.padded = torch.zeros((self.max_rows * world_size, hsize, 3), dtype=torch.float64, device=device)
+                self.image = self.padded[:vsize]
+            else:
+                self.image = torch.zeros((vsize, hsize, 3), dtype=torch.float64, device=device)
 
     def gather(self):
         """All ranks call this after filling `tile`.  Rank 0 returns the assembled (vsize, hsize, 3) image, others None."""
@@ -44,7 +51,5 @@ class FrameGatherer:
         self.dist.gather(self.tile, self.gathered, dst=0)
         if self.rank != 0:
             return None
-        for r in range(N):
-            nr = len(rows_of(r, N, V))
-            self.image[r::N] = self.gathered[r][: nr * H * 3].view(nr, H, 3)
+        self.padded.view(self.max_rows, N, H, 3).copy_(self.slab.permute(1, 0, 2, 3))
         return self.image

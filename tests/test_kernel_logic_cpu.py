@@ -125,3 +125,16 @@ def test_no_device_fails_loudly():
     cam, world = scenes.default_world()
     with pytest.raises(rt.RtwError, match="no HIP device"):
         b.render(b.build_world(world), cam, 5)
+
+
+def test_ppm_writer_matches_oracle_byte_for_byte(orc):
+    """Image::ppm (src/image.rs:93-112) from the product's host formatter vs the oracle's, incl. the reference's two layout tests."""
+    from raytracer_challenge_amd.image import ppm_text
+    rng = np.random.default_rng(3)
+    for (h, v) in ((5, 3), (9, 2), (10, 2), (1, 1), (7, 5), (64, 3)):
+        rgb = rng.uniform(-0.3, 1.3, (h * v, 3))
+        q = orc.quantize(rgb)
+        assert ppm_text(h, v, q) == orc.ppm(h, v, rgb)
+    rgb = np.tile(np.array([[1.0, 0.8, 0.6]]), (18, 1))     # src/image.rs:170-195: 9x2 image splits lines at 5 pixels
+    row5, row4 = "255 204 153 " * 4 + "255 204 153\n", "255 204 153 " * 3 + "255 204 153\n"
+    assert ppm_text(9, 2, orc.quantize(rgb)) == "P3\n9 2\n255\n" + row5 + row4 + row5 + row4

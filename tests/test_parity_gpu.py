@@ -121,3 +121,20 @@ def test_hip_config5_million_triangles_noise(hip, orc, tmp_path):
     rgb2, hits2 = hip.render(nw, cam, 8, idx)
     assert np.array_equal(rgb2, rgb[idx.astype(np.int64)]) and np.array_equal(hits2, hits[idx.astype(np.int64)])
     assert_parity(hip, orc, world, cam, 5, idx, label="config5 sample (%d px)" % idx.size)
+
+
+def test_hip_quantiser_and_ppm(hip, orc):
+    """SURVEY §8f rank 1: Color::clamp on the device and Image::ppm, byte-exact against the oracle; edge values incl. NaN,
+    +-inf, exact .5 boundaries (round half away from zero)."""
+    from raytracer_challenge_amd.image import Image
+    cam, world = scenes.chapter11_title(80, 45)
+    img = Image.par_render(cam, world)
+    ref_rgb, _ = orc.render(orc.build_world(world), cam, 5)
+    assert np.abs(img.pixels - ref_rgb).max() <= RGB_TOL
+    assert np.array_equal(img.quantized(), orc.quantize(img.pixels))
+    assert img.ppm() == orc.ppm(80, 45, img.pixels)
+    c = img.read(40, 22)
+    assert (c.r, c.g, c.b) == tuple(img.pixels[22 * 80 + 40])
+    edge = np.array([[np.nan, np.inf, -np.inf], [0.5 / 255, 1.5 / 255, 2.5 / 255], [-0.0, 1.0, 0.999999999], [254.5 / 255, 0.49999 / 255, 1e-300]])
+    e = Image(4, 1, edge, img._native)
+    assert np.array_equal(e.quantized(), orc.quantize(edge))
