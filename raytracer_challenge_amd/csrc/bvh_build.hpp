@@ -22,6 +22,7 @@ struct Builder {
   uint32_t base;                 // global offset of this BVH's first packed item
   int max_depth = 0;
   bool median_only = false;  // fallback when SAH produced a tree deeper than the traversal stack
+  double center[3] = {0, 0, 0};  // node boxes are stored relative to this point (the BVH's frame, see slab32 on the device)
   static constexpr int kBins = 16;
   int kLeaf = 4;  // max items per leaf (<= 8: 3 bits in the leaf ref)
 
@@ -48,13 +49,13 @@ struct Builder {
     if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
     return f;
   }
-  static void store(const Range& r, float* lo, float* hi) {
+  void store(const Range& r, float* lo, float* hi) const {
     double ext = 0.0;
     for (int a = 0; a < 3; a++) ext = std::max(ext, r.hi[a] - r.lo[a]);
     for (int a = 0; a < 3; a++) {
       double pl = 1e-9 * (std::fabs(r.lo[a]) + ext) + 1e-30, ph = 1e-9 * (std::fabs(r.hi[a]) + ext) + 1e-30;
-      lo[a] = down(r.lo[a] - pl);
-      hi[a] = up(r.hi[a] + ph);
+      lo[a] = down((r.lo[a] - pl) - center[a]);
+      hi[a] = up((r.hi[a] + ph) - center[a]);
     }
   }
   static void store_absent(float* lo, float* hi) {
@@ -157,10 +158,22 @@ struct Builder {
 };
 
 // Returns the root node index (always an inner node, so traversal can start from a node).
+// frame[4] receives the BVH's centre (x, y, z) and the inf-norm radius of its bounds around that centre.
 inline int32_t build(const std::vector<Item>& items, std::vector<DBvhNode>& nodes, std::vector<uint32_t>& order, uint32_t base, int* depth, bool median_only = false,
-                     int leaf_max = 4) {
+                     int leaf_max = 4, double* frame = nullptr) {
   Builder B{items, nodes, order, base};
   B.median_only = median_only;
+  {
+    Builder::Range all = Builder::none();
+    for (const Item& it : items) Builder::grow(all, it);
+    double rad = 0.0;
+    for (int a = 0; a < 3; a++) {
+      B.center[a] = items.empty() ? 0.0 : 0.5 * (all.lo[a] + all.hi[a]);
+      if (!std::isfinite(B.center[a])) B.center[a] = 0.0;
+      if (!items.empty()) rad = std::max(rad, std::max(std::fabs(all.hi[a] - B.center[a]), std::fabs(all.lo[a] - B.center[a])));
+    }
+    if (frame) { frame[0] = B.center[0]; frame[1] = B.center[1]; frame[2] = B.center[2]; frame[3] = rad * (1.0 + 1e-6) + 1e-30; }
+  }
   B.kLeaf = leaf_max < 1 ? 1 : (leaf_max > 8 ? 8 : leaf_max);
   std::vector<uint32_t> ids(items.size());
   for (uint32_t i = 0; i < ids.size(); i++) ids[i] = i;
@@ -170,7 +183,7 @@ inline int32_t build(const std::vector<Item>& items, std::vector<DBvhNode>& node
     int32_t self = (int32_t)nodes.size();
     nodes.emplace_back();
     DBvhNode& N = nodes[self];
-    Builder::store(r, N.lo0, N.hi0);
+    B.store(r, N.lo0, N.hi0);
     Builder::store_absent(N.lo1, N.hi1);
     N.c0 = ref;
     N.c1 = ref;

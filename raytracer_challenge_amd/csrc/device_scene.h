@@ -5,6 +5,7 @@
 // primitive children replaced by a results-neutral accelerator.  A ray walks the array once:
 //   OP_GROUP  a = group box index, b = pc to jump to when BoundingBox::intersects rejects the ray
 //   OP_PRIM   a = primitive index (exact test, own world->object matrix)
+//   (OP_MESH / OP_BVH: c = index of the BVH's frame in bvh_frame)
 //   OP_MESH   a = BVH root, b = xform index: triangles sharing one matrix; ray transformed once, BVH in
 //             object space, leaves index the packed triangle arrays (mtri / mtri_prim)
 //   OP_BVH    a = BVH root: world-space BVH over analytic primitives; leaves index item_prim
@@ -71,6 +72,7 @@ struct DScene {
   const int32_t* quirk_prim; // OP_QUIRK items -> primitive index (cubes, cones)
   const DQuirkGrid* qgrids;
   const uint32_t* qcell;     // per-cell offsets into qitem
+  const double* bvh_frame;   // per BVH (DOp.c of OP_MESH / OP_BVH): centre xyz + inf-norm radius; node boxes are relative to the centre
   const int32_t* qitem;      // primitive indices
   const DPrim* prims;
   const double* xf_inv;      // n_xforms x 12 (rows 0..2 of Shape.transform_inv)

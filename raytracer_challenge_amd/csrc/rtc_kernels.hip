@@ -318,24 +318,52 @@ __device__ __forceinline__ void quirk_grid_scan(const DScene& S, const DQuirkGri
 }
 
 // ---- accelerator -------------------------------------------------------------------------------------
-// Slab test against an f32 box widened at build time; evaluated in f64, NaN-ignoring min/max, so a box is
-// only rejected when the ray's line misses it or its [tn, tf] misses [tlo, thi].  Returns entry distance.
-__device__ __forceinline__ bool slab(const float* __restrict__ lo, const float* __restrict__ hi, const Ray& o, double ix, double iy, double iz,
-                                     double tlo, double thi, double& tn_out) {
-  double t0 = ((double)lo[0] - o.ox) * ix, t1 = ((double)hi[0] - o.ox) * ix;
-  double tn = fmin(t0, t1), tf = fmax(t0, t1);
-  t0 = ((double)lo[1] - o.oy) * iy; t1 = ((double)hi[1] - o.oy) * iy;
-  tn = fmax(tn, fmin(t0, t1)); tf = fmin(tf, fmax(t0, t1));
-  t0 = ((double)lo[2] - o.oz) * iz; t1 = ((double)hi[2] - o.oz) * iz;
-  tn = fmax(tn, fmin(t0, t1)); tf = fmin(tf, fmax(t0, t1));
+// ---- f32 slab test in the BVH's own frame (culling only) ------------------------------------------------
+// Node boxes are f32, stored relative to the BVH's centre c and already widened at build time.  Per ray and BVH:
+//   of  = fl32(o - c)                     (the f64 subtraction is exact to 2^-53, the rounding to f32 costs 2^-24 |o - c|)
+//   eps = 2^-20 (|of|_inf + R)            R = radius of the BVH around c: >= 16x every f32 rounding error of the test,
+//                                         each of which is bounded by 2^-23 times a coordinate or a distance travelled
+//   every box is inflated by eps by testing its low faces against of + eps and its high faces against of - eps,
+//   and the pass's t interval is widened by 2^-18 relative.
+// So a box is rejected only if the f64 ray misses the box inflated by ~15 eps or its [tn, tf] misses [t_lo, t_hi]; NaN
+// (0 * inf) operands are ignored by fminf/fmaxf exactly as in the f64 version.  A ray whose origin does not fit f32
+// relative to c takes every box (id = 0 makes every slab interval [0, 0]).
+struct Frame32 {
+  float olx, oly, olz, ohx, ohy, ohz, ix, iy, iz;
+};
+__device__ __forceinline__ void make_frame(const double* __restrict__ fr, const Ray& o, Frame32& f) {
+  float ox = (float)(o.ox - fr[0]), oy = (float)(o.oy - fr[1]), oz = (float)(o.oz - fr[2]);
+  float m = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + (float)fr[3];
+  if (!(m < 1e30f)) {
+    f.olx = f.oly = f.olz = f.ohx = f.ohy = f.ohz = 0.0f;
+    f.ix = f.iy = f.iz = 0.0f;
+    return;
+  }
+  float eps = m * 9.5367431640625e-07f + 1e-30f;
+  f.olx = ox + eps; f.oly = oy + eps; f.olz = oz + eps;
+  f.ohx = ox - eps; f.ohy = oy - eps; f.ohz = oz - eps;
+  f.ix = 1.0f / (float)o.dx; f.iy = 1.0f / (float)o.dy; f.iz = 1.0f / (float)o.dz;
+}
+__device__ __forceinline__ void t_interval32(const Trav& T, float& lo, float& hi) {
+  const double SL = 3.814697265625e-06;  // 2^-18
+  lo = (T.tlo == -DINF) ? -__builtin_inff() : (float)(T.tlo - SL * fmax(fabs(T.tlo), 1.0));
+  hi = (T.thi == DINF) ? __builtin_inff() : (float)(T.thi + SL * fmax(fabs(T.thi), 1.0));
+}
+__device__ __forceinline__ bool slab32(const float* __restrict__ lo, const float* __restrict__ hi, const Frame32& f, float tlo, float thi, float& tn_out) {
+  float t0 = (lo[0] - f.olx) * f.ix, t1 = (hi[0] - f.ohx) * f.ix;
+  float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+  t0 = (lo[1] - f.oly) * f.iy; t1 = (hi[1] - f.ohy) * f.iy;
+  tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+  t0 = (lo[2] - f.olz) * f.iz; t1 = (hi[2] - f.ohz) * f.iz;
+  tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
   tn_out = tn;
-  return fmax(tn, tlo) <= fmin(tf, thi) && lo[0] <= hi[0];
+  return fmaxf(tn, tlo) <= fminf(tf, thi) && lo[0] <= hi[0];
 }
 
 template <bool MESH>
-__device__ __forceinline__ void bvh_walk(const DScene& S, int root, const Ray& world, const Ray& o, Trav& T, Counters& C, int* __restrict__ stack, int stride) {
-  // t-interval slack: the exact tests and the slab test round differently
-  const double ix = 1.0 / o.dx, iy = 1.0 / o.dy, iz = 1.0 / o.dz;
+__device__ __forceinline__ void bvh_walk(const DScene& S, int root, int frame, const Ray& world, const Ray& o, Trav& T, Counters& C, int* __restrict__ stack, int stride) {
+  Frame32 F;
+  make_frame(S.bvh_frame + 4 * frame, o, F);
   int sp = 0;
   int cur = root;
   for (;;) {
@@ -344,11 +372,10 @@ __device__ __forceinline__ void bvh_walk(const DScene& S, int root, const Ray& w
       DIAG_LOOP(3);
       const DBvhNode* N = S.bvh + cur;
       C.accel_nodes++;
-      double slack = 1e-7 * fmax(fabs(T.thi), 1.0);
-      double lo = T.tlo - ((T.tlo == -DINF) ? 0.0 : 1e-7 * fmax(fabs(T.tlo), 1.0)), hi = (T.thi == DINF) ? DINF : T.thi + slack;
-      double n0, n1;
-      bool h0 = slab(N->lo0, N->hi0, o, ix, iy, iz, lo, hi, n0);
-      bool h1 = slab(N->lo1, N->hi1, o, ix, iy, iz, lo, hi, n1);
+      float lo, hi, n0, n1;
+      t_interval32(T, lo, hi);
+      bool h0 = slab32(N->lo0, N->hi0, F, lo, hi, n0);
+      bool h1 = slab32(N->lo1, N->hi1, F, lo, hi, n1);
       int c0 = N->c0, c1 = N->c1;
       if (h0 && h1) {
         if (n1 < n0) { int tmp = c0; c0 = c1; c1 = tmp; }
@@ -399,10 +426,10 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
       pc = group_box_hit(S.group_box + 6 * op.a, r) ? pc + 1 : op.b;
     } else if (op.op == OP_MESH) {
       Ray o = to_object(S.xf_inv + 12 * op.b, r);
-      bvh_walk<true>(S, op.a, r, o, T, C, stack, stride);
+      bvh_walk<true>(S, op.a, op.c, r, o, T, C, stack, stride);
       pc++;
     } else {
-      bvh_walk<false>(S, op.a, r, r, T, C, stack, stride);
+      bvh_walk<false>(S, op.a, op.c, r, r, T, C, stack, stride);
       pc++;
     }
     if (T.mode == MODE_SHADOW_ANY && T.shadowed) return;
@@ -1027,7 +1054,7 @@ enum { CI_PRIM = 0, CI_PEND = 1 };
 
 struct Lane {  // register-resident state of one lane
   Ray r;              // ray in the space of the structure being walked (world, or object space inside OP_MESH)
-  double ix, iy, iz;  // 1/direction while inside a BVH
+  Frame32 F;          // f32 slab frame of the BVH being walked
   Trav T;
   int pc, cur, sp;    // program counter, BVH cursor (CUR_NONE = at op level, CUR_END = BVH drained), stack depth
   int it, it_end, it_kind;  // pending leaf / list items [it, it_end) and where their primitive ids come from
@@ -1109,7 +1136,7 @@ __device__ __forceinline__ void step_op(const DScene& S, Lane& L, Counters& C, c
     L.pc = group_box_hit(S.group_box + 6 * op.a, L.r) ? L.pc + 1 : op.b;
   } else if (op.op == OP_MESH || op.op == OP_BVH) {
     if (op.op == OP_MESH) { L.r = to_object(S.xf_inv + 12 * op.b, L.r); L.in_mesh = 1; }
-    L.ix = 1.0 / L.r.dx; L.iy = 1.0 / L.r.dy; L.iz = 1.0 / L.r.dz;
+    make_frame(S.bvh_frame + 4 * op.c, L.r, L.F);
     L.cur = op.a;
     L.sp = 0;
   } else if (op.op == OP_QUIRK) {
@@ -1145,11 +1172,10 @@ __device__ __forceinline__ void step_inner(const DScene& S, Lane& L, Counters& C
   if ((unsigned)L.cur >= (unsigned)S.n_bvh) { guard_trip(L, S, gmask, G_NODE); return; }
   const DBvhNode* N = S.bvh + L.cur;
   C.accel_nodes++;
-  double lo = L.T.tlo - ((L.T.tlo == -DINF) ? 0.0 : 1e-7 * fmax(fabs(L.T.tlo), 1.0));
-  double hi = (L.T.thi == DINF) ? DINF : L.T.thi + 1e-7 * fmax(fabs(L.T.thi), 1.0);
-  double n0, n1;
-  bool h0 = slab(N->lo0, N->hi0, L.r, L.ix, L.iy, L.iz, lo, hi, n0);
-  bool h1 = slab(N->lo1, N->hi1, L.r, L.ix, L.iy, L.iz, lo, hi, n1);
+  float lo, hi, n0, n1;
+  t_interval32(L.T, lo, hi);
+  bool h0 = slab32(N->lo0, N->hi0, L.F, lo, hi, n0);
+  bool h1 = slab32(N->lo1, N->hi1, L.F, lo, hi, n1);
   int c0 = N->c0, c1 = N->c1;
   if (h0 && h1) {
     if (n1 < n0) { int tmp = c0; c0 = c1; c1 = tmp; }
@@ -1211,7 +1237,8 @@ __global__ void __launch_bounds__(RTC_WAVE, RTC_V2_WAVES_PER_SIMD) rtc_persist_k
   L.phase = PH_IDLE; L.stage = ST_CLOSEST; L.light = 0; L.fuel = 0; L.np = 0; L.kind = 0; L.q = 0;
   L.pc = 0; L.cur = CUR_NONE; L.sp = 0; L.in_mesh = 0; L.it = 0; L.it_end = 0; L.it_kind = IT_DIRECT;
   L.acc_r = L.acc_g = L.acc_b = 0.0; L.weight = 1.0;
-  L.r.ox = L.r.oy = L.r.oz = L.r.dx = L.r.dy = L.r.dz = 0.0; L.ix = L.iy = L.iz = 0.0;
+  L.r.ox = L.r.oy = L.r.oz = L.r.dx = L.r.dy = L.r.dz = 0.0;
+  L.F.olx = L.F.oly = L.F.olz = L.F.ohx = L.F.ohy = L.F.ohz = L.F.ix = L.F.iy = L.F.iz = 0.0f;
   reset_closest(L.T, MODE_CLOSEST);
   bool first_hit_pending = false;
   unsigned gmask = 0;

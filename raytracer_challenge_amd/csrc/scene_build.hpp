@@ -30,6 +30,7 @@ struct ProgramBuilder {
   std::vector<int32_t>&item_prim = items, &quirk_prim = items, &qitem = items;
   std::vector<DQuirkGrid> qgrids;
   std::vector<uint32_t> qcell;
+  std::vector<double> bvh_frame;  // per BVH: centre xyz + inf-norm radius (DOp.c indexes it)
   int max_depth = 0;
   std::string error;
   int status = RTC_OK;
@@ -169,15 +170,18 @@ struct ProgramBuilder {
     const char* e = std::getenv(mesh ? "RTC_LEAF_MESH" : "RTC_LEAF_ANALYTIC");
     return e ? std::atoi(e) : (mesh ? 4 : 1);
   }
-  int32_t build_tree(const std::vector<bvh::Item>& items, std::vector<uint32_t>& order, uint32_t base, bool mesh) {
+  int32_t build_tree(const std::vector<bvh::Item>& items, std::vector<uint32_t>& order, uint32_t base, bool mesh, int32_t* frame_index) {
     int depth = 0;
     size_t n0 = bvh_nodes.size(), o0 = order.size();
-    int32_t root = bvh::build(items, bvh_nodes, order, base, &depth, false, leaf_size(mesh));
+    double frame[4];
+    int32_t root = bvh::build(items, bvh_nodes, order, base, &depth, false, leaf_size(mesh), frame);
     if (depth > RTC_BVH_STACK - 2) {
       bvh_nodes.resize(n0);
       order.resize(o0);
-      root = bvh::build(items, bvh_nodes, order, base, &depth, true, leaf_size(mesh));
+      root = bvh::build(items, bvh_nodes, order, base, &depth, true, leaf_size(mesh), frame);
     }
+    *frame_index = (int32_t)(bvh_frame.size() / 4);
+    bvh_frame.insert(bvh_frame.end(), frame, frame + 4);
     max_depth = std::max(max_depth, depth);
     return root;
   }
@@ -209,14 +213,15 @@ struct ProgramBuilder {
       if (items.size() < kMinAccel) { for (int32_t pi : ids) rest.push_back(pi); continue; }
       std::vector<uint32_t> order;
       uint32_t base = (uint32_t)mtri_prim.size();
-      int32_t root = build_tree(items, order, base, true);
+      int32_t fi = 0;
+      int32_t root = build_tree(items, order, base, true, &fi);
       for (uint32_t k : order) {
         int32_t pi = ids[k];
         const double* g = D.tri_p1e1e2 + 9 * (size_t)D.prims[pi].data;
         mtri.insert(mtri.end(), g, g + 9);
         mtri_prim.push_back(pi);
       }
-      ops.push_back({OP_MESH, root, kv.first, (int32_t)items.size()});
+      ops.push_back({OP_MESH, root, kv.first, fi});
     }
     // 2. remaining bounded primitives -> one world-space BVH; unbounded ones stay linear
     {
@@ -232,9 +237,10 @@ struct ProgramBuilder {
       if (!items.empty()) {
         std::vector<uint32_t> order;
         uint32_t base = (uint32_t)item_prim.size();
-        int32_t root = build_tree(items, order, base, false);
+        int32_t fi = 0;
+        int32_t root = build_tree(items, order, base, false, &fi);
         for (uint32_t k : order) item_prim.push_back(ids[k]);
-        ops.push_back({OP_BVH, root, 0, (int32_t)items.size()});
+        ops.push_back({OP_BVH, root, 0, fi});
         int32_t q0 = (int32_t)quirk_prim.size();
         for (int32_t pi : ids)
           if (D.prims[pi].geometry == RTC_CUBE || D.prims[pi].geometry == RTC_CONE) quirk_prim.push_back(pi);
@@ -322,6 +328,7 @@ struct HostArrays {
   std::vector<int32_t> mtri_prim, items;  // items: BVH leaf items + quirk lists + grid cells, absolute indices
   std::vector<DQuirkGrid> qgrids;
   std::vector<uint32_t> qcell;
+  std::vector<double> bvh_frame;
   std::vector<DPrim> prims;
   std::vector<double> xf_inv, xf_matinv, limits, tri_geo, tri_nrm, mat;
   std::vector<int32_t> mat_pattern;
@@ -332,7 +339,7 @@ struct HostArrays {
   DScene view() const {
     DScene d{};
     d.ops = ops.data(); d.group_box = group_box.data(); d.bvh = bvh.data(); d.mtri = mtri.data(); d.mtri_prim = mtri_prim.data();
-    d.item_prim = items.data(); d.quirk_prim = items.data(); d.qgrids = qgrids.data(); d.qcell = qcell.data(); d.qitem = items.data(); d.prims = prims.data(); d.xf_inv = xf_inv.data(); d.xf_matinv = xf_matinv.data(); d.limits = limits.data();
+    d.item_prim = items.data(); d.quirk_prim = items.data(); d.qgrids = qgrids.data(); d.qcell = qcell.data(); d.bvh_frame = bvh_frame.data(); d.qitem = items.data(); d.prims = prims.data(); d.xf_inv = xf_inv.data(); d.xf_matinv = xf_matinv.data(); d.limits = limits.data();
     d.tri_geo = tri_geo.data(); d.tri_nrm = tri_nrm.data(); d.mat = mat.data(); d.mat_pattern = mat_pattern.data(); d.pats = pats.data();
     d.lights = lights.data();
     d.n_ops = (int32_t)ops.size(); d.n_prims = (int32_t)prims.size(); d.n_lights = n_lights; d.all_cast_shadow = all_cast_shadow;
@@ -401,6 +408,7 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
   H->items = std::move(pb.items);
   H->qgrids = std::move(pb.qgrids);
   H->qcell = std::move(pb.qcell);
+  H->bvh_frame = std::move(pb.bvh_frame);
   H->bvh_depth = pb.max_depth;
   return RTC_OK;
 }

@@ -131,6 +131,18 @@ def edge_rays(n=4096, seed=7):
     return np.concatenate([o, d], axis=1)
 
 
+def far_rays(n=1024, seed=11, distances=(1e3, 1e5, 1e7)):
+    """Rays that start 10^3..10^7 units away and aim at random points inside the scene: the accelerator's f32 slab test works
+    in a BVH-local frame with a per-ray error bound that grows with the origin's distance; hits must stay bit-exact."""
+    rng = np.random.default_rng(seed)
+    target = rng.uniform(-3, 3, (n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dist = np.array(distances)[rng.integers(0, len(distances), n)][:, None]
+    o = target - d * dist
+    return np.concatenate([o, d], axis=1)
+
+
 SMALL_CASES = {
     "default_world": lambda: scenes.default_world(),
     "glass_air_bubble_200x100": lambda: scenes.chapter11_glass_air_bubble(200, 100),   # BASELINE config 1

@@ -16,6 +16,9 @@
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 struct uint3_ { unsigned x, y, z; };
 typedef void* hipStream_t;
+using std::fabs; using std::floor;
+// fminf/fmaxf/fabsf come from <cmath> (C functions, NaN-ignoring like the device versions)
+#define EMU_PLACEHOLDER
 using std::fabs; using std::floor; using std::fmax; using std::fmin; using std::pow; using std::sqrt;
 
 #ifndef RTC_EMU_SIMT

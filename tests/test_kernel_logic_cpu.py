@@ -138,3 +138,9 @@ def test_ppm_writer_matches_oracle_byte_for_byte(orc):
     rgb = np.tile(np.array([[1.0, 0.8, 0.6]]), (18, 1))     # src/image.rs:170-195: 9x2 image splits lines at 5 pixels
     row5, row4 = "255 204 153 " * 4 + "255 204 153\n", "255 204 153 " * 3 + "255 204 153\n"
     assert ppm_text(9, 2, orc.quantize(rgb)) == "P3\n9 2\n255\n" + row5 + row4 + row5 + row4
+
+
+def test_emulated_kernel_far_rays(emu, orc):
+    for name in ("all_primitives", "cube_lattice", "synthetic_mesh_small", "synthetic_cones_grouped"):
+        _, world = cases.SMALL_CASES[name]()
+        assert_ray_parity(emu, orc, world, cases.far_rays(512), 5, label="far " + name)

@@ -138,3 +138,9 @@ def test_hip_quantiser_and_ppm(hip, orc):
     edge = np.array([[np.nan, np.inf, -np.inf], [0.5 / 255, 1.5 / 255, 2.5 / 255], [-0.0, 1.0, 0.999999999], [254.5 / 255, 0.49999 / 255, 1e-300]])
     e = Image(4, 1, edge, img._native)
     assert np.array_equal(e.quantized(), orc.quantize(edge))
+
+
+def test_hip_far_rays(hip, orc):
+    for name in ("all_primitives", "cube_lattice", "synthetic_mesh_small", "synthetic_cones_grouped"):
+        _, world = cases.SMALL_CASES[name]()
+        assert_ray_parity(hip, orc, world, cases.far_rays(2048), 5, label="far " + name)
