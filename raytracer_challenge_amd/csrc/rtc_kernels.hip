@@ -764,9 +764,8 @@ __device__ __forceinline__ Ray camera_ray(const DCamera& cam, uint64_t i) {
 // and the pixels a lane fetches later, stay spatially close; a work id that falls outside the image is skipped.
 struct WorkMap {
   uint64_t n_work;      // number of work ids
-  uint32_t tiled, tiles_x, width, height;  // tiles_x counts 16x16 super-tiles per row when tiled
+  uint32_t tiled, tiles_x, width, height;
 };
-#define RTC_V3_CHUNK 256   // work ids owned by one v3 block: one 16x16 super-tile = four 8x8 tiles
 __device__ __forceinline__ WorkMap make_workmap(const DPixelMap& pm, const DCamera& cam) {
   WorkMap w;
   w.tiled = 0; w.tiles_x = 0; w.width = 0; w.height = 0; w.n_work = pm.n;
@@ -774,19 +773,17 @@ __device__ __forceinline__ WorkMap make_workmap(const DPixelMap& pm, const DCame
     w.tiled = 1;
     w.width = (uint32_t)cam.hsize;
     w.height = (uint32_t)(pm.n / cam.hsize);
-    w.tiles_x = (w.width + 15u) / 16u;
-    w.n_work = (uint64_t)w.tiles_x * ((w.height + 15u) / 16u) * 256u;
+    w.tiles_x = (w.width + 7u) / 8u;
+    w.n_work = (uint64_t)w.tiles_x * ((w.height + 7u) / 8u) * 64u;
   }
   return w;
 }
 // work id -> output slot q (row-major within the launch's pixel set); false if the id is padding.
 __device__ __forceinline__ bool work_to_slot(const WorkMap& w, uint64_t id, uint64_t& q) {
   if (!w.tiled) { q = id; return true; }
-  uint64_t st = id >> 8;                       // 16x16 super-tile
-  uint32_t sub = (uint32_t)(id >> 6) & 3u;     // which 8x8 tile inside it
+  uint64_t tile = id >> 6;
   uint32_t in = (uint32_t)(id & 63u);
-  uint32_t x = (uint32_t)(st % w.tiles_x) * 16u + (sub & 1u) * 8u + (in & 7u);
-  uint32_t y = (uint32_t)(st / w.tiles_x) * 16u + (sub >> 1) * 8u + (in >> 3);
+  uint32_t x = (uint32_t)(tile % w.tiles_x) * 8u + (in & 7u), y = (uint32_t)(tile / w.tiles_x) * 8u + (in >> 3);
   if (x >= w.width || y >= w.height) return false;
   q = (uint64_t)y * w.width + x;
   return true;
@@ -809,9 +806,9 @@ __device__ __forceinline__ Ray slot_ray(const DPixelMap& pm, const DCamera& cam,
 
 // v1/v3: one lane walks one pixel's ray tree at a time (closest pass, shading, shadow passes, pending children).
 // REFILL = false (v1): one pixel per lane, the wave ends with its slowest pixel.
-// REFILL = true  (v3): a block owns a 16x16 super-tile (256 work ids); a lane that finishes its pixel takes the next id of
-//   the block from an LDS counter and keeps iterating the same ray loop (refill at ray granularity): the per-pixel cost
-//   imbalance is averaged over 4x more pixels while the wave stays on spatially adjacent pixels.
+// REFILL = true  (v3): a lane that finishes its pixel immediately takes the next work id from a global counter and
+//   keeps iterating the same ray loop, so the wave's lanes stay busy until the frame runs out (persistent waves,
+//   refill at ray granularity); the grid is sized to the resident wave count.
 template <bool COUNT, bool REFILL>
 __global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD) rtc_trace_kernel(DScene S, DCamera cam, DPixelMap pm, int fuel0, double* __restrict__ rgb, double* __restrict__ hit_t,
                                                         int* __restrict__ hit_prim, int* __restrict__ hit_k, DStats* __restrict__ stats,
@@ -828,22 +825,14 @@ __global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD) rtc_trace_kerne
   const unsigned long long diag_k0 = __builtin_amdgcn_s_memtime();
 #endif
 
-  // v1: one work id per lane.  v3 (REFILL): the block owns RTC_V3_CHUNK consecutive ids (one 16x16 super-tile when tiled);
-  // lanes start on the first 64 and take further ids from a block-local LDS counter, so a wave stays on its own tile.
-  __shared__ unsigned lds_next;
-  const uint64_t chunk_base = REFILL ? (uint64_t)blockIdx.x * RTC_V3_CHUNK : 0;
-  const uint64_t chunk_end = REFILL ? ((chunk_base + RTC_V3_CHUNK < wm.n_work) ? chunk_base + RTC_V3_CHUNK : wm.n_work) : wm.n_work;
-  if (REFILL) {
-    if (threadIdx.x == 0) lds_next = blockDim.x;
-    __syncthreads();
-  }
-  uint64_t id = REFILL ? chunk_base + threadIdx.x : (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // first work id of this lane, then (REFILL) ids from the counter, which starts at gridDim.x * blockDim.x
+  uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t q = 0;
   bool have = false;
-  while (id < chunk_end) {
+  while (id < wm.n_work) {
     if (work_to_slot(wm, id, q)) { have = true; break; }
     if (!REFILL) break;
-    id = chunk_base + atomicAdd(&lds_next, 1u);
+    id = atomicAdd(next_work, 1ull);
   }
 
   if (have) {
@@ -997,8 +986,8 @@ __global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD) rtc_trace_kerne
         if (!REFILL) break;
         bool more = false;
         for (;;) {
-          id = chunk_base + atomicAdd(&lds_next, 1u);
-          if (id >= chunk_end) break;
+          id = atomicAdd(next_work, 1ull);
+          if (id >= wm.n_work) break;
           if (work_to_slot(wm, id, q)) { more = true; break; }
         }
         if (!more) break;
@@ -1566,10 +1555,8 @@ void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, 
                       DStats* stats, bool count, hipStream_t stream, unsigned refill_blocks, unsigned long long* next_work) {
   if (pm.n == 0) return;
   dim3 block(RTC_BLOCK);
-  if (refill_blocks) {  // v3: one block per chunk of RTC_V3_CHUNK work ids, block-local refill
-    uint64_t nw = pm.n;
-    if (pm.mode == 2 && cam.hsize >= 8 && pm.n % cam.hsize == 0) nw = (uint64_t)((cam.hsize + 15) / 16) * ((pm.n / cam.hsize + 15) / 16) * 256;
-    dim3 grid((unsigned)((nw + RTC_V3_CHUNK - 1) / RTC_V3_CHUNK));
+  if (refill_blocks) {  // v3: persistent grid; next_work was set to refill_blocks * RTC_BLOCK by the caller
+    dim3 grid(refill_blocks);
     if (count) hipLaunchKernelGGL((rtc_trace_kernel<true, true>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
     else hipLaunchKernelGGL((rtc_trace_kernel<false, true>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
     return;
@@ -1577,7 +1564,7 @@ void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, 
   // v1: one lane per work id (tile padding included)
   uint64_t n_work = pm.n;
   if (pm.mode == 2 && cam.hsize >= 8 && pm.n % cam.hsize == 0)
-    n_work = (uint64_t)((cam.hsize + 15) / 16) * ((pm.n / cam.hsize + 15) / 16) * 256;
+    n_work = (uint64_t)((cam.hsize + 7) / 8) * ((pm.n / cam.hsize + 7) / 8) * 64;
   dim3 grid((unsigned)((n_work + RTC_BLOCK - 1) / RTC_BLOCK));
   if (count) hipLaunchKernelGGL((rtc_trace_kernel<true, false>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
   else hipLaunchKernelGGL((rtc_trace_kernel<false, false>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);

@@ -13,7 +13,6 @@
 #define __noinline__
 #define __shared__ static
 #define __launch_bounds__(...)
-#define EMU_HAS_SYNCTHREADS 1
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 struct uint3_ { unsigned x, y, z; };
 typedef void* hipStream_t;
@@ -27,7 +26,6 @@ using std::fabs; using std::floor; using std::fmax; using std::fmin; using std::
 static uint3_ blockIdx, threadIdx, blockDim, gridDim;
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
-static inline void __syncthreads() {}
 static inline unsigned long long __ballot(int p) { return p ? 1ull : 0ull; }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
@@ -69,7 +67,6 @@ static inline void barrier() {
 }  // namespace emu_simt
 template <class T> static inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 template <class T> static inline T atomicOr(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
-static inline void __syncthreads() { emu_simt::barrier(); }
 static inline unsigned long long __ballot(int p) {
   using namespace emu_simt;
   unsigned k = g_ballot_no++;
