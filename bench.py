@@ -3,7 +3,9 @@
 1/2/4/8-GPU scaling").
 
 A *step* is one full frame: every rank traces its interleaved rows of the 1920x1080 image (fuel 5) with the HIP
-kernels and, for N > 1, the tiles are gathered to rank 0 over RCCL and de-interleaved.  Rays are *unique* rays
+kernels and, for N > 1, the tiles are gathered to rank 0 over RCCL and de-interleaved.  Frames are software-pipelined
+(double-buffered tiles): the render of frame i overlaps the gather of frame i-1; all K renders and K gathers happen
+inside the timed region.  Rays are *unique* rays
 (SURVEY.md §8d): primary + shadow + reflection + refraction casts, counted by the kernel's counting variant in an
 untimed pass (the count is deterministic).  Total work is fixed as N grows -> "strong" scaling.
 
@@ -11,8 +13,8 @@ untimed pass (the count is deterministic).  Total work is fixed as N grows -> "s
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes of the dominant (only) kernel per launch
-(SURVEY.md §8d formula on the kernel's own counters) / its average duration measured with HIP events on the stream it
-is launched on.  `cpu_baseline` = the CPU oracle (C++ restatement of the reference algorithm, NOT the Rust reference)
+(SURVEY.md §8d formula on the kernel's own counters) / its average duration: HIP events recorded on the stream the
+kernel is launched on around the K launches of the timed region, / K.  `cpu_baseline` = the CPU oracle (C++ restatement of the reference algorithm, NOT the Rust reference)
 timed on a bounded pixel sample of the same workload.
 """
 import argparse
@@ -132,32 +134,47 @@ def main():
     from raytracer_challenge_amd.parallel import FrameGatherer
     fg = FrameGatherer(H, V, rank, world_size, dev, dist)
 
-    def step(count=False):
-        st = dr.render_rows(args.fuel, rank, world_size, fg.n_rows, fg.tile, count=count, sync=True)
+    def finish(i):
+        """Frame i: wait for its render (marker i % 2), then gather its tiles to rank 0 (RCCL) and de-interleave."""
+        dr.wait(i % 2)
         if world_size > 1:
-            fg.gather()
-        return st
+            fg.gather(i % 2)
+            torch.cuda.current_stream().synchronize()  # tiles[i % 2] is free again once the gather has consumed it
+
+    def run_frames(k):
+        """k full frames, software-pipelined: the render of frame i overlaps the gather of frame i-1."""
+        for i in range(k):
+            dr.render_rows_async(args.fuel, rank, world_size, fg.n_rows, fg.tiles[i % 2])
+            dr.record(i % 2)
+            if i > 0:
+                finish(i - 1)
+        if k > 0:
+            finish(k - 1)
 
     # untimed: counting variant -> unique rays + algorithmic bytes of this rank's launch
-    cst = step(count=True)
+    cst = dr.render_rows(args.fuel, rank, world_size, fg.n_rows, fg.tiles[0], count=True, sync=True)
     rays_local = torch.tensor([float(cst["unique_rays"])], dtype=torch.float64, device=dev)
     if world_size > 1:
         dist.all_reduce(rays_local)
     rays_total = float(rays_local.item())
 
-    for _ in range(args.warmup):
-        step()
+    run_frames(args.warmup)
+    dr.check()
     if world_size > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    kernel_ms = []
+    dr.sync()
+    dr.record(2)                      # stream markers 2..3 bracket the timed region's launches on the kernel's own stream
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        kernel_ms.append(step()["kernel_ms"])
+    run_frames(args.steps)
+    dr.record(3)
+    dr.sync()
     torch.cuda.synchronize()
     if world_size > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    dr.check()                        # NaN / guard flags of the timed launches
+    kernel_ms = [dr.elapsed_ms(2, 3) / max(1, args.steps)]
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world_size > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)

@@ -177,6 +177,15 @@ int rtc_quantize(rtc_scene*, const double* rgb, uint64_t n_values, uint8_t* out)
  * writes only if cap is large enough. */
 uint64_t rtc_ppm(uint64_t hsize, uint64_t vsize, const uint8_t* rgb8, char* out, uint64_t cap);
 
+/* Waits for the stream and returns the error state (RTC_ERR_NAN / RTC_ERR_DEVICE) of the LAST launch; asynchronous
+ * launches (sync == 0, stats == NULL) do not report it themselves. */
+int rtc_scene_check(rtc_scene*);
+/* Stream markers for pipelined hosts: record marker `slot` (0..7) behind everything queued so far on the scene's stream;
+ * wait for it on the host; device time between two recorded markers in ms. */
+int rtc_scene_record(rtc_scene*, int slot);
+int rtc_scene_wait(rtc_scene*, int slot);
+int rtc_scene_elapsed_ms(rtc_scene*, int slot_from, int slot_to, double* ms);
+
 /* Blocks until the scene's stream is idle. */
 int rtc_scene_sync(rtc_scene*);
 

@@ -43,6 +43,7 @@ struct rtc_scene {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t marker[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   std::vector<void*> allocs;
   uint64_t bytes = 0;
   DScene d{};
@@ -204,6 +205,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
   HIP_OK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   HIP_OK(hipEventCreate(&s->ev0));
   HIP_OK(hipEventCreate(&s->ev1));
+  for (auto& m : s->marker) HIP_OK(hipEventCreate(&m));
 
   DScene& d = s->d;
 #define UP(field)                                                       \
@@ -282,6 +284,7 @@ void rtc_scene_destroy(rtc_scene* s) {
   if (s->d_ctx_i) (void)hipFree(s->d_ctx_i);
   if (s->d_idx) (void)hipFree(s->d_idx);
   if (s->d_rays) (void)hipFree(s->d_rays);
+  for (auto& m : s->marker) if (m) (void)hipEventDestroy(m);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -437,6 +440,38 @@ uint64_t rtc_ppm(uint64_t hsize, uint64_t vsize, const uint8_t* rgb8, char* out,
   *p++ = '\n';
   *p = 0;
   return (uint64_t)(p - out);
+}
+
+// Error flags of the launches since the last check (asynchronous launches do not read them back themselves).
+int rtc_scene_check(rtc_scene* s) {
+  if (!s) return rtc_fail(RTC_ERR_INVALID, "NULL scene");
+  HIP_OK(hipSetDevice(s->device));
+  HIP_OK(hipStreamSynchronize(s->stream));
+  DStats h;
+  HIP_OK(hipMemcpy(&h, s->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+  if (h.guard) return rtc_fail(RTC_ERR_DEVICE, "traversal guard tripped (mask " + std::to_string(h.guard) + ")");
+  if (h.nan_ts) return rtc_fail(RTC_ERR_NAN, "a NaN intersection t was produced (the reference panics in Intersection::sort, src/intersection.rs:124)");
+  return RTC_OK;
+}
+
+int rtc_scene_record(rtc_scene* s, int slot) {
+  if (!s || slot < 0 || slot >= 8) return rtc_fail(RTC_ERR_INVALID, "bad marker slot");
+  HIP_OK(hipSetDevice(s->device));
+  HIP_OK(hipEventRecord(s->marker[slot], s->stream));
+  return RTC_OK;
+}
+int rtc_scene_wait(rtc_scene* s, int slot) {
+  if (!s || slot < 0 || slot >= 8) return rtc_fail(RTC_ERR_INVALID, "bad marker slot");
+  HIP_OK(hipSetDevice(s->device));
+  HIP_OK(hipEventSynchronize(s->marker[slot]));
+  return RTC_OK;
+}
+int rtc_scene_elapsed_ms(rtc_scene* s, int from, int to, double* ms) {
+  if (!s || !ms || from < 0 || from >= 8 || to < 0 || to >= 8) return rtc_fail(RTC_ERR_INVALID, "bad marker slot");
+  float f = 0.f;
+  HIP_OK(hipEventElapsedTime(&f, s->marker[from], s->marker[to]));
+  *ms = f;
+  return RTC_OK;
 }
 
 int rtc_scene_sync(rtc_scene* s) {

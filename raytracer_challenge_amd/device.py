@@ -59,6 +59,13 @@ class DeviceRenderer:
                                                C.c_void_p, C.POINTER(RtcStatsC), C.c_int, C.c_int]
         lib.rtc_scene_sync.restype = C.c_int
         lib.rtc_scene_sync.argtypes = [C.c_void_p]
+        for name in ("rtc_scene_record", "rtc_scene_wait"):
+            getattr(lib, name).restype = C.c_int
+            getattr(lib, name).argtypes = [C.c_void_p, C.c_int]
+        lib.rtc_scene_check.restype = C.c_int
+        lib.rtc_scene_check.argtypes = [C.c_void_p]
+        lib.rtc_scene_elapsed_ms.restype = C.c_int
+        lib.rtc_scene_elapsed_ms.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         lib.rtc_last_error.restype = C.c_char_p
         lib.rtc_scene_device_bytes.restype = C.c_uint64
         lib.rtc_scene_device_bytes.argtypes = [C.c_void_p]
@@ -85,6 +92,32 @@ class DeviceRenderer:
         if rc != 0:
             raise RtwError("rtc_render_rows_device: %s" % (self.backend.lib.rtc_last_error() or b"").decode())
         return st.as_dict() if want_stats else {}
+
+    def _rc(self, rc, what):
+        if rc != 0:
+            raise RtwError("%s: %s" % (what, (self.backend.lib.rtc_last_error() or b"").decode()))
+
+    def render_rows_async(self, fuel: int, row_first: int, row_step: int, n_rows: int, out_tensor):
+        """Queue a render on the scene's stream and return immediately (errors are reported by check())."""
+        need = n_rows * self.camera.hsize * 3
+        if out_tensor.numel() < need or out_tensor.element_size() != 8 or not out_tensor.is_cuda:
+            raise RtwError("output tensor must be a float64 device tensor with >= %d elements" % need)
+        self._rc(self.backend.lib.rtc_render_rows_device(self.scene, C.byref(self.cam), int(fuel), int(row_first), int(row_step), int(n_rows),
+                                                        C.c_void_p(out_tensor.data_ptr()), None, 0, 0), "rtc_render_rows_device")
+
+    def record(self, slot: int):
+        self._rc(self.backend.lib.rtc_scene_record(self.scene, slot), "rtc_scene_record")
+
+    def wait(self, slot: int):
+        self._rc(self.backend.lib.rtc_scene_wait(self.scene, slot), "rtc_scene_wait")
+
+    def elapsed_ms(self, slot_from: int, slot_to: int) -> float:
+        ms = C.c_double(0.0)
+        self._rc(self.backend.lib.rtc_scene_elapsed_ms(self.scene, slot_from, slot_to, C.byref(ms)), "rtc_scene_elapsed_ms")
+        return ms.value
+
+    def check(self):
+        self._rc(self.backend.lib.rtc_scene_check(self.scene), "rtc_scene_check")
 
     def sync(self):
         self.backend.lib.rtc_scene_sync(self.scene)

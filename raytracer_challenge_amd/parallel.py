@@ -28,7 +28,9 @@ class FrameGatherer:
         self.hsize, self.vsize, self.rank, self.world_size, self.dist = hsize, vsize, rank, world_size, dist
         self.n_rows = len(rows_of(rank, world_size, vsize))
         self.max_rows = max_rows(world_size, vsize)
-        self.tile = torch.zeros(self.max_rows * hsize * 3, dtype=torch.float64, device=device)
+        # two tiles: frame i renders into tiles[i % 2] while frame i-1 is gathered from the other one
+        self.tiles = [torch.zeros(self.max_rows * hsize * 3, dtype=torch.float64, device=device) for _ in range(2)]
+        self.tile = self.tiles[0]
         self.gathered: Optional[List] = None
         self.image = None
         if rank == 0:
@@ -42,13 +44,14 @@ class FrameGatherer:
             else:
                 self.image = torch.zeros((vsize, hsize, 3), dtype=torch.float64, device=device)
 
-    def gather(self):
-        """All ranks call this after filling `tile`.  Rank 0 returns the assembled (vsize, hsize, 3) image, others None."""
+    def gather(self, which: int = 0):
+        """All ranks call this after tiles[which] is complete.  Rank 0 returns the assembled (vsize, hsize, 3) image, others None."""
         H, V, N = self.hsize, self.vsize, self.world_size
+        tile = self.tiles[which]
         if N == 1:
-            self.image.view(-1)[:] = self.tile[: V * H * 3]
+            self.image.view(-1)[:] = tile[: V * H * 3]
             return self.image
-        self.dist.gather(self.tile, self.gathered, dst=0)
+        self.dist.gather(tile, self.gathered, dst=0)
         if self.rank != 0:
             return None
         self.padded.view(self.max_rows, N, H, 3).copy_(self.slab.permute(1, 0, 2, 3))

@@ -107,6 +107,10 @@ int rtc_trace_rays(rtc_scene* s, const double* rays, uint64_t n, int32_t fuel, d
 int rtc_quantize_device(rtc_scene*, const double* rgb, uint64_t n, uint8_t* out, int) { rtc_launch_quantize(rgb, out, n, nullptr); return RTC_OK; }
 int rtc_quantize(rtc_scene* s, const double* rgb, uint64_t n, uint8_t* out) { return rtc_quantize_device(s, rgb, n, out, 1); }
 int rtc_scene_sync(rtc_scene*) { return RTC_OK; }
+int rtc_scene_check(rtc_scene*) { return RTC_OK; }
+int rtc_scene_record(rtc_scene*, int) { return RTC_OK; }
+int rtc_scene_wait(rtc_scene*, int) { return RTC_OK; }
+int rtc_scene_elapsed_ms(rtc_scene*, int, int, double* ms) { if (ms) *ms = 0.0; return RTC_OK; }
 void rtc_scene_accel_info(const rtc_scene* s, uint32_t* n_ops, uint32_t* n_bvh_nodes, uint32_t* n_mesh_tris, uint32_t* bvh_depth) {
   if (n_ops) *n_ops = (uint32_t)s->H.ops.size();
   if (n_bvh_nodes) *n_bvh_nodes = (uint32_t)s->H.bvh.size();
