@@ -72,14 +72,35 @@ struct ProgramBuilder {
     if (!local_bounds(p, lo, hi)) return false;
     rth::M4 inv = rth::M4::from(D.xforms[p.xform].transform_inv), fwd;
     if (!inv.invert(&fwd)) return false;
-    for (int a = 0; a < 3; a++) { out->lo[a] = rth::kInf; out->hi[a] = -rth::kInf; }
-    for (int k = 0; k < 8; k++) {
-      rth::V4 c = fwd.apply(rth::pt((k & 4) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], (k & 1) ? hi[2] : lo[2]));
-      double q[3] = {c.x, c.y, c.z};
+    const double(*F)[4] = fwd.a;
+    bool tight = false;
+    if (p.geometry == RTC_SPHERE || p.geometry == RTC_CYLINDER || p.geometry == RTC_CONE) {
+      // Exact AABB of the image of a solid of revolution about the object y axis: along world axis i the unit disc in the
+      // object xz plane spans +-sqrt(F_i0^2 + F_i2^2) (times the largest radius), the sphere +-|row i of the 3x3 part|, and the
+      // axis segment y in [ylo, yhi] spans F_i1 * y.  Tighter than the 8 corners of the object-space box by up to sqrt(3).
+      double r = 1.0, ylo = 0.0, yhi = 0.0;
+      if (p.geometry != RTC_SPHERE) { ylo = lo[1]; yhi = hi[1]; r = hi[0]; }
+      tight = true;
       for (int a = 0; a < 3; a++) {
-        if (!std::isfinite(q[a])) return false;
-        out->lo[a] = std::fmin(out->lo[a], q[a]);
-        out->hi[a] = std::fmax(out->hi[a], q[a]);
+        double c = F[a][3], e;
+        if (p.geometry == RTC_SPHERE) e = std::sqrt(F[a][0] * F[a][0] + F[a][1] * F[a][1] + F[a][2] * F[a][2]);
+        else e = r * std::sqrt(F[a][0] * F[a][0] + F[a][2] * F[a][2]);
+        double s0 = F[a][1] * ylo, s1 = F[a][1] * yhi;
+        out->lo[a] = c + std::fmin(s0, s1) - e;
+        out->hi[a] = c + std::fmax(s0, s1) + e;
+        if (!std::isfinite(out->lo[a]) || !std::isfinite(out->hi[a])) tight = false;
+      }
+    }
+    if (!tight) {
+      for (int a = 0; a < 3; a++) { out->lo[a] = rth::kInf; out->hi[a] = -rth::kInf; }
+      for (int k = 0; k < 8; k++) {
+        rth::V4 c = fwd.apply(rth::pt((k & 4) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], (k & 1) ? hi[2] : lo[2]));
+        double q[3] = {c.x, c.y, c.z};
+        for (int a = 0; a < 3; a++) {
+          if (!std::isfinite(q[a])) return false;
+          out->lo[a] = std::fmin(out->lo[a], q[a]);
+          out->hi[a] = std::fmax(out->hi[a], q[a]);
+        }
       }
     }
     // the forward matrix is a numerical inverse of an inverse: widen by its conditioning-independent slop
