@@ -14,12 +14,15 @@
 //   OP_QGRID  a = index into qgrids: the same scan, culled by ray DIRECTION: whether a ray is a quirk ray for a cube /
 //             cone depends only on its direction (thin bands on the direction sphere), so a cube-map grid of
 //             directions lists, per cell, the few primitives whose band can touch the cell
+//   OP_CSG    a = group box index, b = pc of the matching OP_CSG_END, c = index into csg[]: a Union / Intersection / Difference
+//             group (src/shape.rs:161-178, :257-266).  Its subtree follows as a LINEAR sub-program (OP_PRIM, OP_GROUP, nested
+//             OP_CSG ... OP_CSG_END; no accelerator inside).  OP_CSG_END c = the same csg index.
 // The accelerator may only skip primitives whose exact test would not produce an intersection with t inside
 // the interval the current pass cares about, so hit records are independent of it.
 #pragma once
 #include <stdint.h>
 
-enum { OP_PRIM = 0, OP_GROUP = 1, OP_MESH = 2, OP_BVH = 3, OP_QUIRK = 4, OP_QGRID = 5 };
+enum { OP_PRIM = 0, OP_GROUP = 1, OP_MESH = 2, OP_BVH = 3, OP_QUIRK = 4, OP_QGRID = 5, OP_CSG = 6, OP_CSG_END = 7 };
 
 struct DOp {
   int32_t op, a, b, c;
@@ -42,6 +45,14 @@ struct DQuirkGrid {
   int32_t n, cell_off, lin_first, lin_count;
 };
 #define RTC_QGRID_MIN_LEN 0.05
+
+// One CSG group: kind (RTC_NODE_UNION / _INTERSECTION / _DIFFERENCE) and the primitive range of children[0] (DFS order makes
+// "children[0].includes(shape)" a range test on the sequence number).
+struct DCsg {
+  int32_t kind, left_first, left_end, pad;
+};
+#define RTC_CSG_MAX_HITS 32   // intersections one top-level CSG subtree can produce (checked at scene creation)
+#define RTC_CSG_MAX_DEPTH 8
 
 struct DPrim {  // 32 bytes
   int32_t geom;
@@ -72,6 +83,7 @@ struct DScene {
   const int32_t* quirk_prim; // OP_QUIRK items -> primitive index (cubes, cones)
   const DQuirkGrid* qgrids;
   const uint32_t* qcell;     // per-cell offsets into qitem
+  const DCsg* csg;
   const double* bvh_frame;   // per BVH (DOp.c of OP_MESH / OP_BVH): centre xyz + inf-norm radius; node boxes are relative to the centre
   const int32_t* qitem;      // primitive indices
   const DPrim* prims;
@@ -87,6 +99,7 @@ struct DScene {
   int32_t n_ops, n_prims, n_lights;
   int32_t all_cast_shadow;   // 1: every primitive casts a shadow -> shadow rays may stop at any hit
   int32_t has_mesh;          // 1: the program contains an OP_MESH
+  int32_t has_csg;           // 1: the program contains an OP_CSG
   // array lengths, for the traversal guards (a bad index retires the lane and raises DStats.guard instead of faulting)
   int32_t n_bvh, n_items, n_mtri, n_quirk, n_qitem, n_qcell, n_groups, n_qgrids;
 };

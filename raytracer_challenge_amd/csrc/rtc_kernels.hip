@@ -120,11 +120,13 @@ __device__ __forceinline__ bool key_before(double t, int prim, int k, double ht,
   return (t < ht) || (t == ht && (prim < hprim || (prim == hprim && k < hk)));
 }
 
-__device__ __forceinline__ void accept(Trav& T, Counters& C, int prim, int n, const double* t) {
+// `ks` (optional) = the original push index of each entry, when a CSG filter has dropped some of a primitive's pushes.
+__device__ __forceinline__ void accept(Trav& T, Counters& C, int prim, int n, const double* t, const int* ks = nullptr) {
   if (n == 0) return;
   if (T.mode == MODE_CLOSEST || T.mode == MODE_SHADOW_CLOSEST) {
-    for (int k = 0; k < n; k++) {
-      double tk = t[k];
+    for (int j = 0; j < n; j++) {
+      const int k = ks ? ks[j] : j;
+      double tk = t[j];
       if (tk != tk) C.nan_ts++;
       if (tk >= 0.0) {
         if (tk < T.best_t || (tk == T.best_t && prim < T.best_prim)) {
@@ -144,8 +146,9 @@ __device__ __forceinline__ void accept(Trav& T, Counters& C, int prim, int n, co
   } else {  // MODE_CONTAINERS
     int cnt1 = 0, cnt2 = 0;
     double m1 = 0.0, m2 = 0.0;
-    for (int k = 0; k < n; k++) {
-      double tk = t[k];
+    for (int j = 0; j < n; j++) {
+      const int k = ks ? ks[j] : j;
+      double tk = t[j];
       bool b1 = key_before(tk, prim, k, T.thi, T.best_prim, T.best_klast);
       bool b2 = b1 || (tk == T.thi && prim == T.best_prim && k == T.best_klast);
       // pushes of one primitive arrive in push order, so ">=" keeps the latest push among equal t
@@ -405,6 +408,79 @@ __device__ __forceinline__ void bvh_walk(const DScene& S, int root, int frame, c
   }
 }
 
+// ---- CSG groups (src/shape.rs:161-178 allows_intersection, :230-246 filter_by_group, :257-266 Group::intersect) ------------
+// ops[pc] is an OP_CSG.  The subtree's sub-program is walked once; every primitive's pushes go to a per-lane buffer in
+// insertion order; at each OP_CSG_END the node's range of the buffer is stable-sorted by t and filtered in place — post-order,
+// so a nested CSG hands its parent exactly the list the reference's recursion would.  What survives the outermost filter is
+// fed to the current pass with each entry's own (primitive, push index), so tie-breaks and the container pass see the same keys.
+struct CsgHit { double t; int prim, k; };
+__device__ __noinline__ int csg_eval(const DScene& S, int pc, const Ray& r, Trav& T, Counters& C) {
+  CsgHit buf[RTC_CSG_MAX_HITS];
+  int n = 0;
+  int frame_begin[RTC_CSG_MAX_DEPTH];
+  int depth = 0;
+  const int end_pc = S.ops[pc].b;  // the matching OP_CSG_END
+  int p = pc;
+  while (p <= end_pc) {
+    DOp op = S.ops[p];
+    if (op.op == OP_CSG) {
+      C.group_tests++;
+      if (!group_box_hit(S.group_box + 6 * op.a, r)) { p = op.b + 1; continue; }  // whole node contributes nothing
+      frame_begin[depth++] = n;
+      p++;
+    } else if (op.op == OP_GROUP) {
+      C.group_tests++;
+      p = group_box_hit(S.group_box + 6 * op.a, r) ? p + 1 : op.b;
+    } else if (op.op == OP_PRIM) {
+      DPrim P = S.prims[op.a];
+      Ray o = to_object(S.xf_inv + 12 * P.xform, r);
+      double t[4], u = 0.0, v = 0.0;
+      if (P.geom >= 5) C.tri_tests++; else C.analytic_tests++;
+      int m = prim_hits(S, P, o, t, u, v);
+      for (int j = 0; j < m && n < RTC_CSG_MAX_HITS; j++) {
+        if (t[j] != t[j]) C.nan_ts++;  // the reference sorts this list: a NaN t panics (src/intersection.rs:124)
+        buf[n].t = t[j]; buf[n].prim = op.a; buf[n].k = j; n++;
+      }
+      p++;
+    } else {  // OP_CSG_END: sort [b, n) by t (stable: insertion sort), then filter_by_group
+      const DCsg G = S.csg[op.c];
+      int b = frame_begin[--depth];
+      for (int i = b + 1; i < n; i++) {
+        CsgHit h = buf[i];
+        int j = i - 1;
+        while (j >= b && buf[j].t > h.t) { buf[j + 1] = buf[j]; j--; }
+        buf[j + 1] = h;
+      }
+      bool in_left = false, in_right = false;
+      int w = b;
+      for (int i = b; i < n; i++) {
+        bool left_hit = buf[i].prim >= G.left_first && buf[i].prim < G.left_end;
+        bool keep;
+        if (G.kind == 0) keep = (left_hit && !in_right) || (!left_hit && !in_left);         // Union
+        else if (G.kind == 1) keep = (left_hit && in_right) || (!left_hit && in_left);      // Intersection
+        else keep = (left_hit && !in_right) || (!left_hit && in_left);                      // Difference
+        if (left_hit) in_left = !in_left; else in_right = !in_right;
+        if (keep) buf[w++] = buf[i];
+      }
+      n = w;
+      p++;
+    }
+  }
+  // hand the retained intersections to the pass, one primitive at a time (its entries keep their relative order)
+  for (int i = 0; i < n; i++) {
+    int prim = buf[i].prim;
+    bool seen = false;
+    for (int j = 0; j < i; j++) seen = seen || buf[j].prim == prim;
+    if (seen) continue;
+    double t[8];
+    int ks[8], m = 0;
+    for (int j = i; j < n && m < 8; j++)
+      if (buf[j].prim == prim) { t[m] = buf[j].t; ks[m] = buf[j].k; m++; }
+    accept(T, C, prim, m, t, ks);
+  }
+  return end_pc + 1;
+}
+
 // World::intersect (src/world.rs:18-24) + Group::intersect (src/shape.rs:248-269) over the flattened program.
 __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T, Counters& C, int* __restrict__ stack, int stride) {
   int pc = 0;
@@ -424,6 +500,8 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
     } else if (op.op == OP_GROUP) {
       C.group_tests++;
       pc = group_box_hit(S.group_box + 6 * op.a, r) ? pc + 1 : op.b;
+    } else if (op.op == OP_CSG) {
+      pc = csg_eval(S, pc, r, T, C);
     } else if (op.op == OP_MESH) {
       Ray o = to_object(S.xf_inv + 12 * op.b, r);
       bvh_walk<true>(S, op.a, op.c, r, o, T, C, stack, stride);

@@ -219,7 +219,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     d.quirk_prim = d.item_prim;
     d.qitem = d.item_prim;
   }
-  UP(qgrids); UP(qcell); UP(bvh_frame); UP(prims); UP(xf_inv); UP(xf_matinv); UP(limits);
+  UP(qgrids); UP(qcell); UP(bvh_frame); UP(csg); UP(prims); UP(xf_inv); UP(xf_matinv); UP(limits);
   UP(tri_geo); UP(tri_nrm); UP(mat); UP(mat_pattern); UP(pats); UP(lights);
 #undef UP
   d.n_ops = (int32_t)H.ops.size();
@@ -229,6 +229,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
   {
     DScene hv = H.view();
     d.has_mesh = hv.has_mesh;
+    d.has_csg = hv.has_csg;
     d.n_bvh = hv.n_bvh; d.n_items = hv.n_items; d.n_mtri = hv.n_mtri; d.n_quirk = hv.n_quirk;
     d.n_qitem = hv.n_qitem; d.n_qcell = hv.n_qcell; d.n_groups = hv.n_groups; d.n_qgrids = hv.n_qgrids;
   }
@@ -264,6 +265,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     int per_cu = rtc_v2_waves_per_cu();
     if (const char* w = std::getenv("RTC_V2_WAVES_PER_CU")) per_cu = std::max(1, std::atoi(w));
     s->max_waves = (unsigned)std::max(1, n_cu * per_cu);
+    if (s->d.has_csg && s->kernel_version == 2) s->kernel_version = 1;  // the step machine of v2 has no CSG step; v1/v3 do
     int per_cu3 = rtc_v3_blocks_per_cu();
     if (const char* w = std::getenv("RTC_V3_BLOCKS_PER_CU")) per_cu3 = std::max(1, std::atoi(w));
     s->max_blocks_v3 = (unsigned)std::max(1, n_cu * per_cu3);

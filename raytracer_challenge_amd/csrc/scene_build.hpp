@@ -31,6 +31,7 @@ struct ProgramBuilder {
   std::vector<DQuirkGrid> qgrids;
   std::vector<uint32_t> qcell;
   std::vector<double> bvh_frame;  // per BVH: centre xyz + inf-norm radius (DOp.c indexes it)
+  std::vector<DCsg> csg;
   int max_depth = 0;
   std::string error;
   int status = RTC_OK;
@@ -207,6 +208,69 @@ struct ProgramBuilder {
     return root;
   }
 
+  // Most intersections a primitive can push (src/shape.rs:608-619, :667-678, :746-767 + caps :689-722).
+  static int max_hits(int geometry) { return geometry == RTC_CYLINDER || geometry == RTC_CONE ? 4 : (geometry == RTC_SPHERE || geometry == RTC_CUBE ? 2 : 1); }
+
+  // Linear sub-program of a subtree that lives inside a CSG group: every node in DFS order, no accelerator.
+  bool emit_linear(uint32_t b, uint32_t e, int depth, int* hits) {
+    for (uint32_t i = b; i < e;) {
+      const rtc_node& n = D.nodes[i];
+      if (n.skip <= (int32_t)i || (uint32_t)n.skip > e) { error = "node skip out of range"; status = RTC_ERR_INVALID; return false; }
+      if (n.kind == RTC_NODE_PRIM) {
+        ops.push_back({OP_PRIM, n.ref, 0, 0});
+        *hits += max_hits(D.prims[n.ref].geometry);
+      } else if (n.kind == RTC_NODE_AGGREGATION) {
+        int32_t gi = (int32_t)(group_box.size() / 6);
+        group_box.insert(group_box.end(), n.bbox_min, n.bbox_min + 3);
+        group_box.insert(group_box.end(), n.bbox_max, n.bbox_max + 3);
+        size_t at = ops.size();
+        ops.push_back({OP_GROUP, gi, 0, 0});
+        if (!emit_linear(i + 1, (uint32_t)n.skip, depth, hits)) return false;
+        ops[at].b = (int32_t)ops.size();
+      } else {
+        if (!emit_csg(i, depth + 1, hits)) return false;
+      }
+      i = (uint32_t)n.skip;
+    }
+    return true;
+  }
+
+  // A Union / Intersection / Difference group (src/shape.rs:74-101 asserts exactly two children).
+  bool emit_csg(uint32_t i, int depth, int* outer_hits = nullptr) {
+    const rtc_node& n = D.nodes[i];
+    if (depth >= RTC_CSG_MAX_DEPTH) { error = "CSG groups nested deeper than RTC_CSG_MAX_DEPTH"; status = RTC_ERR_UNSUPPORTED; return false; }
+    // children: first child = node i+1, second = the node after the first child's subtree
+    uint32_t c0 = i + 1, end = (uint32_t)n.skip;
+    if (c0 >= end) { error = "CSG group without children"; status = RTC_ERR_INVALID; return false; }
+    uint32_t c1 = (uint32_t)D.nodes[c0].skip;
+    if (c1 >= end || (uint32_t)D.nodes[c1].skip != end) { error = "CSG group kinds take exactly two children (src/shape.rs:82)"; status = RTC_ERR_INVALID; return false; }
+    auto first_prim = [&](uint32_t from) {  // sequence number of the first primitive at or after node `from`
+      for (uint32_t k = from; k < D.n_nodes; k++)
+        if (D.nodes[k].kind == RTC_NODE_PRIM) return D.nodes[k].ref;
+      return (int32_t)D.n_prims;
+    };
+    DCsg rec{n.kind, first_prim(c0), first_prim(c1), 0};
+    // an empty left subtree (groups without primitives) has left_first == left_end: nothing is "in the left child"
+    int32_t ci = (int32_t)csg.size();
+    csg.push_back(rec);
+    int32_t gi = (int32_t)(group_box.size() / 6);
+    group_box.insert(group_box.end(), n.bbox_min, n.bbox_min + 3);
+    group_box.insert(group_box.end(), n.bbox_max, n.bbox_max + 3);
+    size_t at = ops.size();
+    ops.push_back({OP_CSG, gi, 0, ci});
+    int hits = 0;
+    if (!emit_linear(c0, end, depth, &hits)) return false;
+    ops[at].b = (int32_t)ops.size();
+    ops.push_back({OP_CSG_END, 0, 0, ci});
+    if (hits > RTC_CSG_MAX_HITS) {
+      error = "a CSG group's subtree can produce more than RTC_CSG_MAX_HITS intersections (device buffer)";
+      status = RTC_ERR_UNSUPPORTED;
+      return false;
+    }
+    if (outer_hits) *outer_hits += hits;
+    return true;
+  }
+
   // Emits the program for the children list nodes[b, e) of one group (or of the world).
   bool emit(uint32_t b, uint32_t e) {
     std::vector<uint32_t> prim_kids, group_kids;
@@ -274,9 +338,8 @@ struct ProgramBuilder {
     for (uint32_t i : group_kids) {
       const rtc_node& n = D.nodes[i];
       if (n.kind != RTC_NODE_AGGREGATION) {
-        error = "CSG group kinds (Union/Intersection/Difference, src/shape.rs:161-178) are not supported on device yet";
-        status = RTC_ERR_UNSUPPORTED;
-        return false;
+        if (!emit_csg(i, 0)) return false;
+        continue;
       }
       int32_t gi = (int32_t)(group_box.size() / 6);
       group_box.insert(group_box.end(), n.bbox_min, n.bbox_min + 3);
@@ -350,6 +413,7 @@ struct HostArrays {
   std::vector<DQuirkGrid> qgrids;
   std::vector<uint32_t> qcell;
   std::vector<double> bvh_frame;
+  std::vector<DCsg> csg;
   std::vector<DPrim> prims;
   std::vector<double> xf_inv, xf_matinv, limits, tri_geo, tri_nrm, mat;
   std::vector<int32_t> mat_pattern;
@@ -360,14 +424,15 @@ struct HostArrays {
   DScene view() const {
     DScene d{};
     d.ops = ops.data(); d.group_box = group_box.data(); d.bvh = bvh.data(); d.mtri = mtri.data(); d.mtri_prim = mtri_prim.data();
-    d.item_prim = items.data(); d.quirk_prim = items.data(); d.qgrids = qgrids.data(); d.qcell = qcell.data(); d.bvh_frame = bvh_frame.data(); d.qitem = items.data(); d.prims = prims.data(); d.xf_inv = xf_inv.data(); d.xf_matinv = xf_matinv.data(); d.limits = limits.data();
+    d.item_prim = items.data(); d.quirk_prim = items.data(); d.qgrids = qgrids.data(); d.qcell = qcell.data(); d.bvh_frame = bvh_frame.data(); d.csg = csg.data(); d.qitem = items.data(); d.prims = prims.data(); d.xf_inv = xf_inv.data(); d.xf_matinv = xf_matinv.data(); d.limits = limits.data();
     d.tri_geo = tri_geo.data(); d.tri_nrm = tri_nrm.data(); d.mat = mat.data(); d.mat_pattern = mat_pattern.data(); d.pats = pats.data();
     d.lights = lights.data();
     d.n_ops = (int32_t)ops.size(); d.n_prims = (int32_t)prims.size(); d.n_lights = n_lights; d.all_cast_shadow = all_cast_shadow;
     d.n_bvh = (int32_t)bvh.size(); d.n_items = (int32_t)items.size(); d.n_mtri = (int32_t)mtri_prim.size(); d.n_quirk = (int32_t)items.size();
     d.n_qitem = (int32_t)items.size(); d.n_qcell = (int32_t)qcell.size(); d.n_groups = (int32_t)(group_box.size() / 6); d.n_qgrids = (int32_t)qgrids.size();
     d.has_mesh = 0;
-    for (const DOp& o : ops) if (o.op == OP_MESH) d.has_mesh = 1;
+    d.has_csg = 0;
+    for (const DOp& o : ops) { if (o.op == OP_MESH) d.has_mesh = 1; if (o.op == OP_CSG) d.has_csg = 1; }
     return d;
   }
 };
@@ -430,6 +495,7 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
   H->qgrids = std::move(pb.qgrids);
   H->qcell = std::move(pb.qcell);
   H->bvh_frame = std::move(pb.bvh_frame);
+  H->csg = std::move(pb.csg);
   H->bvh_depth = pb.max_depth;
   return RTC_OK;
 }

@@ -115,6 +115,39 @@ def synthetic_mesh_small():
     return scenes.synthetic_mesh(path, hsize=48, vsize=27)
 
 
+def csg_scene():
+    """Union / Intersection / Difference groups (src/shape.rs:161-178, :230-269): the classic carved cube, a lens, a union
+    with a glass member (containers see only retained intersections), a CSG nested in a CSG, a CSG inside a transformed
+    aggregation group, and a CSG whose child is an aggregation group."""
+    m = lambda r, g, b, **kw: Material(pattern=Pattern.plain(Color.new(r, g, b)), **kw)
+    carved = Element.composite(Matrix.translation(-3, 1, 0) * Matrix.rotation_y(0.6), None, GroupKind.Difference, [
+        Element.cube(ShapeArgs(material=m(0.9, 0.7, 0.2))),
+        Element.sphere(ShapeArgs(transform=Matrix.scaling(1.3, 1.3, 1.3), material=m(0.8, 0.1, 0.1, reflective=0.3)))])
+    lens = Element.composite(Matrix.translation(0, 1, 0), None, GroupKind.Intersection, [
+        Element.sphere(ShapeArgs(transform=Matrix.translation(-0.5, 0, 0), material=m(0.1, 0.1, 0.2, transparency=0.9, reflective=0.5, refractive_index=1.5, diffuse=0.2))),
+        Element.sphere(ShapeArgs(transform=Matrix.translation(0.5, 0, 0), material=m(0.1, 0.2, 0.1, transparency=0.9, reflective=0.5, refractive_index=1.5, diffuse=0.2)))])
+    union_glass = Element.composite(Matrix.translation(3, 1, 0), None, GroupKind.Union, [
+        Element.cylinder(ShapeArgs(transform=Matrix.scaling(0.6, 1, 0.6), material=m(0.2, 0.6, 0.9)), -1.0, 1.0, True),
+        Element.sphere(ShapeArgs(transform=Matrix.translation(0, 0.8, 0), material=m(0.05, 0.05, 0.05, transparency=0.8, reflective=0.4, refractive_index=1.3, diffuse=0.3)))])
+    inner = Element.composite(Matrix.id(), None, GroupKind.Union, [
+        Element.sphere(ShapeArgs(transform=Matrix.translation(0, 0, -0.6) * Matrix.scaling(0.7, 0.7, 0.7), material=m(0.9, 0.9, 0.9))),
+        Element.sphere(ShapeArgs(transform=Matrix.translation(0, 0, 0.6) * Matrix.scaling(0.7, 0.7, 0.7), material=m(0.9, 0.5, 0.9)))])
+    nested = Element.composite(Matrix.translation(-1.5, 1, 3.5), None, GroupKind.Difference, [
+        Element.cube(ShapeArgs(transform=Matrix.scaling(1.0, 0.8, 1.2), material=m(0.3, 0.8, 0.4))), inner])
+    in_group = Element.composite(Matrix.translation(2, 0.8, 3.5) * Matrix.scaling(0.8, 0.8, 0.8), m(0.9, 0.4, 0.1, specular=0.5), GroupKind.Aggregation, [
+        Element.composite(Matrix.rotation_x(0.5), None, GroupKind.Difference, [Element.cone(ShapeArgs(), -1.0, 0.0, True), Element.cube(ShapeArgs(transform=Matrix.translation(0.9, -0.5, 0)))]),
+        Element.sphere(ShapeArgs(transform=Matrix.translation(0, 1.0, 0) * Matrix.scaling(0.4, 0.4, 0.4)))])
+    agg_child = Element.composite(Matrix.translation(5.5, 1, 2), None, GroupKind.Intersection, [
+        Element.composite(Matrix.id(), None, GroupKind.Aggregation, [
+            Element.sphere(ShapeArgs(transform=Matrix.translation(-0.4, 0, 0), material=m(0.7, 0.7, 0.2))),
+            Element.sphere(ShapeArgs(transform=Matrix.translation(0.4, 0, 0), material=m(0.2, 0.7, 0.7)))]),
+        Element.cube(ShapeArgs(transform=Matrix.scaling(1.2, 0.5, 1.2), material=m(0.6, 0.3, 0.6)))])
+    floor = Element.plane(ShapeArgs(material=Material(pattern=Pattern.checkers(Matrix.id(), Pattern.plain(Color.new(0.8, 0.8, 0.8)), Pattern.plain(Color.new(0.3, 0.3, 0.3))), reflective=0.1)))
+    return _cam(96, 54, 1.0, (1.0, 5.0, -9.0), (1.0, 0.8, 1.0)), World(
+        [PointLight(Color.white(), Vector.point(-6, 9, -7)), PointLight(Color.new(0.4, 0.4, 0.5), Vector.point(8, 6, -3))],
+        [floor, carved, lens, union_glass, nested, in_group, agg_child])
+
+
 def edge_rays(n=4096, seed=7):
     """Rays for color_at parity: random, axis-parallel (the |d|<EPSILON slab rule), grazing, starting inside shapes, zero-ish components."""
     rng = np.random.default_rng(seed)
@@ -158,4 +191,5 @@ SMALL_CASES = {
     "nested_groups": nested_groups,
     "cube_lattice": cube_lattice,
     "synthetic_mesh_small": synthetic_mesh_small,
+    "csg_scene": csg_scene,
 }

@@ -60,7 +60,7 @@ def test_emulated_kernel_fuel(emu, orc, fuel):
 
 
 def test_emulated_kernel_edge_rays(emu, orc):
-    for name in ("all_primitives", "nested_glass", "nested_groups", "cube_lattice", "synthetic_cones_grouped"):
+    for name in ("all_primitives", "nested_glass", "nested_groups", "cube_lattice", "synthetic_cones_grouped", "csg_scene"):
         _, world = cases.SMALL_CASES[name]()
         assert_ray_parity(emu, orc, world, cases.edge_rays(2048), 5, label=name)
 
@@ -110,9 +110,10 @@ def test_host_errors_and_flatten(emu):
     assert b.lib.rtw_world_flatten_counts(nw.handle, counts) == 0
     n_nodes, n_prims, n_xforms, n_limits, n_tris, n_materials, n_pats, n_lights = list(counts)
     assert (n_nodes, n_prims, n_xforms, n_tris, n_lights) == (244, 243, 4, 240, 2) and n_materials == 2
-    # CSG is valid in the reference but not on device: scene creation must say so, not render wrongly
-    csg = World([PointLight(Color.white(), Vector.point(0, 5, -5))], [Element.composite(Matrix.id(), None, GroupKind.Difference, [Element.cube(), Element.sphere()])])
-    with pytest.raises(rt.RtwError, match="not supported on device"):
+    # a CSG subtree that can produce more intersections than the device buffer holds is refused loudly, not rendered wrongly
+    many = Element.composite(Matrix.id(), None, GroupKind.Aggregation, [Element.sphere(ShapeArgs(transform=Matrix.translation(0.1 * i, 0, 0))) for i in range(20)])
+    csg = World([PointLight(Color.white(), Vector.point(0, 5, -5))], [Element.composite(Matrix.id(), None, GroupKind.Difference, [many, Element.sphere()])])
+    with pytest.raises(rt.RtwError, match="RTC_CSG_MAX_HITS"):
         emu.render(emu.build_world(csg), cam, 5)
 
 

@@ -26,7 +26,7 @@ def test_hip_every_kernel_version(hip, orc, version, monkeypatch):
     """RTC_KERNEL selects the kernel at scene creation: 1 = pixel per lane (default), 2 = persistent voted state machine,
     3 = per-lane refill.  All three must be bit-exact in hits on analytic, mesh, grouped and glass scenes."""
     monkeypatch.setenv("RTC_KERNEL", version)
-    for name in ("synthetic_cones_grouped", "teapot_low", "nested_glass", "cube_lattice", "synthetic_mesh_small", "patterns_and_noise"):
+    for name in ("synthetic_cones_grouped", "teapot_low", "nested_glass", "cube_lattice", "synthetic_mesh_small", "patterns_and_noise", "csg_scene"):
         cam, world = cases.SMALL_CASES[name]()
         assert_parity(hip, orc, world, cam, 5, label="kernel v%s %s" % (version, name))
 
@@ -40,7 +40,7 @@ def test_hip_fuel(hip, orc, fuel):
 
 
 def test_hip_edge_rays(hip, orc):
-    for name in ("all_primitives", "nested_glass", "nested_groups", "synthetic_cones_grouped", "cube_lattice"):
+    for name in ("all_primitives", "nested_glass", "nested_groups", "synthetic_cones_grouped", "cube_lattice", "csg_scene"):
         _, world = cases.SMALL_CASES[name]()
         assert_ray_parity(hip, orc, world, cases.edge_rays(4096), 5, label=name)
 
