@@ -482,6 +482,8 @@ __device__ __noinline__ int csg_eval(const DScene& S, int pc, const Ray& r, Trav
 }
 
 // World::intersect (src/world.rs:18-24) + Group::intersect (src/shape.rs:248-269) over the flattened program.
+// CSGK: the kernel instantiation for scenes that contain CSG groups; all others never see the (register-hungry) call.
+template <bool CSGK>
 __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T, Counters& C, int* __restrict__ stack, int stride) {
   int pc = 0;
   const int n = S.n_ops;
@@ -500,7 +502,7 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
     } else if (op.op == OP_GROUP) {
       C.group_tests++;
       pc = group_box_hit(S.group_box + 6 * op.a, r) ? pc + 1 : op.b;
-    } else if (op.op == OP_CSG) {
+    } else if (CSGK && op.op == OP_CSG) {
       pc = csg_eval(S, pc, r, T, C);
     } else if (op.op == OP_MESH) {
       Ray o = to_object(S.xf_inv + 12 * op.b, r);
@@ -887,7 +889,7 @@ __device__ __forceinline__ Ray slot_ray(const DPixelMap& pm, const DCamera& cam,
 // REFILL = true  (v3): a lane that finishes its pixel immediately takes the next work id from a global counter and
 //   keeps iterating the same ray loop, so the wave's lanes stay busy until the frame runs out (persistent waves,
 //   refill at ray granularity); the grid is sized to the resident wave count.
-template <bool COUNT, bool REFILL>
+template <bool COUNT, bool REFILL, bool CSGK>
 __global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD) rtc_trace_kernel(DScene S, DCamera cam, DPixelMap pm, int fuel0, double* __restrict__ rgb, double* __restrict__ hit_t,
                                                         int* __restrict__ hit_prim, int* __restrict__ hit_k, DStats* __restrict__ stats,
                                                         unsigned long long* __restrict__ next_work) {
@@ -931,7 +933,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD) rtc_trace_kerne
       DIAG_T0();
       Trav T;
       reset_closest(T, MODE_CLOSEST);
-      traverse(S, ray, T, C, stack, stride);
+      traverse<CSGK>(S, ray, T, C, stack, stride);
       DIAG_REGION(0);
       bool did_hit = T.best_prim != 0x7fffffff;
       if (first) {
@@ -959,7 +961,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD) rtc_trace_kerne
           K.mode = MODE_CONTAINERS;
           K.tlo = -DINF; K.thi = T.best_t;
           K.c1_prim = -1; K.c2_prim = -1; K.c1_t = 0.0; K.c2_t = 0.0;
-          traverse(S, ray, K, C, stack, stride);
+          traverse<CSGK>(S, ray, K, C, stack, stride);
           if (K.c1_prim >= 0) n1 = S.mat[8 * S.prims[K.c1_prim].mat + 6];
           if (K.c2_prim >= 0) n2 = S.mat[8 * S.prims[K.c2_prim].mat + 6];
           DIAG_REGION(1);
@@ -994,7 +996,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD) rtc_trace_kerne
           reset_closest(Sh, S.all_cast_shadow ? MODE_SHADOW_ANY : MODE_SHADOW_CLOSEST);
           if (S.all_cast_shadow) Sh.thi = distance;
           DIAG_T0();
-          traverse(S, sray, Sh, C, stack, stride);
+          traverse<CSGK>(S, sray, Sh, C, stack, stride);
           DIAG_REGION(3);
           bool shadowed;
           if (S.all_cast_shadow) shadowed = Sh.shadowed != 0;
@@ -1629,14 +1631,22 @@ void rtc_launch_quantize(const double* rgb, unsigned char* out, unsigned long lo
   hipLaunchKernelGGL(rtc_quantize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, rgb, out, n);
 }
 
+template <bool COUNT, bool REFILL>
+static void launch_trace_t(bool csg, dim3 grid, dim3 block, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb,
+                           double* hit_t, int* hit_prim, int* hit_k, DStats* stats, unsigned long long* next_work) {
+  if (csg) hipLaunchKernelGGL((rtc_trace_kernel<COUNT, REFILL, true>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
+  else hipLaunchKernelGGL((rtc_trace_kernel<COUNT, REFILL, false>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
+}
+
 void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
                       DStats* stats, bool count, hipStream_t stream, unsigned refill_blocks, unsigned long long* next_work) {
   if (pm.n == 0) return;
   dim3 block(RTC_BLOCK);
+  const bool csg = S.has_csg != 0;
   if (refill_blocks) {  // v3: persistent grid; next_work was set to refill_blocks * RTC_BLOCK by the caller
     dim3 grid(refill_blocks);
-    if (count) hipLaunchKernelGGL((rtc_trace_kernel<true, true>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
-    else hipLaunchKernelGGL((rtc_trace_kernel<false, true>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
+    if (count) launch_trace_t<true, true>(csg, grid, block, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
+    else launch_trace_t<false, true>(csg, grid, block, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
     return;
   }
   // v1: one lane per work id (tile padding included)
@@ -1644,13 +1654,13 @@ void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, 
   if (pm.mode == 2 && cam.hsize >= 8 && pm.n % cam.hsize == 0)
     n_work = (uint64_t)((cam.hsize + 7) / 8) * ((pm.n / cam.hsize + 7) / 8) * 64;
   dim3 grid((unsigned)((n_work + RTC_BLOCK - 1) / RTC_BLOCK));
-  if (count) hipLaunchKernelGGL((rtc_trace_kernel<true, false>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
-  else hipLaunchKernelGGL((rtc_trace_kernel<false, false>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
+  if (count) launch_trace_t<true, false>(csg, grid, block, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
+  else launch_trace_t<false, false>(csg, grid, block, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
 }
 #ifndef RTC_EMU
 int rtc_v3_blocks_per_cu(void) {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtc_trace_kernel<false, true>, RTC_BLOCK, 0) != hipSuccess || nb <= 0) nb = 4;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtc_trace_kernel<false, true, false>, RTC_BLOCK, 0) != hipSuccess || nb <= 0) nb = 4;
   return nb;
 }
 #endif
