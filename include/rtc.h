@@ -27,7 +27,8 @@ typedef struct rtc_scene rtc_scene;
 enum {
   RTC_OK = 0,
   RTC_ERR_INVALID = 1,     /* malformed description (index out of range, pattern too deep, ...)        */
-  RTC_ERR_UNSUPPORTED = 2, /* valid in the reference, not on device yet (CSG group kinds)             */
+  RTC_ERR_UNSUPPORTED = 2, /* valid in the reference, beyond a device limit (a CSG subtree producing more
+                              than 32 intersections or nested deeper than 8)                            */
   RTC_ERR_DEVICE = 3,      /* HIP failure / no device                                                   */
   RTC_ERR_NAN = 4          /* a NaN intersection t was produced; the reference panics when it sorts it
                               (src/intersection.rs:124)                                                 */
