@@ -75,6 +75,131 @@ def chapter11_title(hsize=None, vsize=None) -> Tuple[Camera, World]:
     return _cam(4096, 2160, 1.152, (-2.6, 1.5, -3.9), (-0.6, 1.0, -0.8), (0.0, 1.0, 0.0), hsize, vsize), world
 
 
+def chapter12_title(hsize=None, vsize=None) -> Tuple[Camera, World]:
+    """src/bin/chapter12_title.rs:14-268 — a room of 18 cubes: checkered floor/walls, table, glass cube, mirror."""
+    def cube(t, rgb=None, pattern=None, **kw):
+        pat = pattern if pattern is not None else Pattern.plain(Color.new(*rgb))
+        return Element.cube(ShapeArgs(transform=t, material=Material(pattern=pat, **kw)))
+
+    T, S, RY = Matrix.translation, Matrix.scaling, Matrix.rotation_y
+    leg_mat = dict(rgb=(0.5529, 0.4235, 0.3255), ambient=0.2, diffuse=0.7)
+    elements = [
+        cube(S(20.0, 7.0, 20.0) * T(0.0, 1.0, 0.0), pattern=Pattern.checkers(S(0.07, 0.07, 0.07), Pattern.plain(Color.black()), Pattern.plain(Color.new(0.25, 0.25, 0.25))),
+             ambient=0.25, diffuse=0.7, specular=0.9, shininess=300.0, reflective=0.1),
+        cube(S(10.0, 10.0, 10.0), pattern=Pattern.checkers(S(0.05, 20.0, 0.05), Pattern.plain(Color.new(0.4863, 0.3765, 0.2941)), Pattern.plain(Color.new(0.3725, 0.2902, 0.2275))),
+             ambient=0.1, diffuse=0.7, specular=0.9, shininess=300.0, reflective=0.1),
+        cube(T(0.0, 3.1, 0.0) * S(3.0, 0.1, 2.0), pattern=Pattern.stripes(RY(0.1) * S(0.05, 0.05, 0.05), Pattern.plain(Color.new(0.5529, 0.4235, 0.3255)), Pattern.plain(Color.new(0.6588, 0.5098, 0.4000))),
+             ambient=0.1, diffuse=0.7, specular=0.9, shininess=300.0, reflective=0.2),
+        cube(T(2.7, 1.5, -1.7) * S(0.1, 1.5, 0.1), **leg_mat),
+        cube(T(2.7, 1.5, 1.7) * S(0.1, 1.5, 0.1), **leg_mat),
+        cube(T(-2.7, 1.5, -1.7) * S(0.1, 1.5, 0.1), **leg_mat),
+        cube(T(-2.7, 1.5, 1.7) * S(0.1, 1.5, 0.1), **leg_mat),
+        cube(T(0.0, 3.45001, 0.0) * RY(0.2) * S(0.25, 0.25, 0.25), (1.0, 1.0, 0.8), ambient=0.0, diffuse=0.3, specular=0.9, shininess=300.0,
+             reflective=0.7, transparency=0.7, refractive_index=1.5),
+        cube(T(1.0, 3.35, -0.9) * RY(-0.4) * S(0.15, 0.15, 0.15), (1.0, 0.5, 0.5), reflective=0.6, diffuse=0.4),
+        cube(T(-1.5, 3.27, 0.3) * RY(0.4) * S(0.15, 0.07, 0.15), (1.0, 1.0, 0.5)),
+        cube(T(0.0, 3.25, 1.0) * RY(0.4) * S(0.2, 0.05, 0.05), (0.5, 1.0, 0.5)),
+        cube(T(-0.6, 3.4, -1.0) * RY(0.8) * S(0.05, 0.2, 0.05), (0.5, 0.5, 1.0)),
+        cube(T(2.0, 3.4, 1.0) * RY(0.8) * S(0.05, 0.2, 0.05), (0.5, 1.0, 1.0)),
+        cube(T(-10.0, 4.0, 1.0) * S(0.05, 1.0, 1.0), (0.7098, 0.2471, 0.2196), diffuse=0.6),
+        cube(T(-10.0, 3.4, 2.7) * S(0.05, 0.4, 0.4), (0.2667, 0.2706, 0.6902), diffuse=0.6),
+        cube(T(-10.0, 4.6, 2.7) * S(0.05, 0.4, 0.4), (0.3098, 0.5961, 0.3098), diffuse=0.6),
+        cube(T(-2.0, 3.5, 9.95) * S(5.0, 1.5, 0.05), (0.3882, 0.2627, 0.1882), diffuse=0.6),
+        cube(T(-2.0, 3.5, 9.95) * S(4.8, 1.4, 0.06), (0.0, 0.0, 0.0), ambient=0.0, diffuse=0.0, specular=1.0, shininess=300.0, reflective=1.0),
+    ]
+    world = World([PointLight(Color.new(1.0, 1.0, 0.9), Vector.point(0.0, 6.9, -5.0))], elements)
+    return _cam(4096, 2160, 0.785, (8.0, 6.0, -8.0), (0.0, 3.0, 0.0), (0.0, 1.0, 0.0), hsize, vsize), world
+
+
+def chapter13_title(hsize=None, vsize=None) -> Tuple[Camera, World]:
+    """src/bin/chapter13_title.rs:14-245 — a checkered plane and ten cylinders (open, closed, concentric, glass)."""
+    T, S, RY = Matrix.translation, Matrix.scaling, Matrix.rotation_y
+
+    def cyl(t, rgb, mn, mx, closed, **kw):
+        return Element.cylinder(ShapeArgs(transform=t, material=Material(pattern=Pattern.plain(Color.new(*rgb)), **kw)), mn, mx, closed)
+
+    shiny = dict(ambient=0.1, specular=0.9, shininess=300.0)
+    floor = Element.plane(ShapeArgs(material=Material(
+        pattern=Pattern.checkers(RY(0.3) * S(0.25, 0.25, 0.25), Pattern.plain(Color.new(0.5, 0.5, 0.5)), Pattern.plain(Color.new(0.75, 0.75, 0.75))),
+        ambient=0.2, diffuse=0.9, specular=0.0)))
+    elements = [
+        floor,
+        cyl(T(-1.0, 0.0, 1.0) * S(0.5, 1.0, 0.5), (0.0, 0.0, 0.6), 0.0, 0.75, True, diffuse=0.1, specular=0.9, shininess=300.0, reflective=0.9),
+        cyl(T(1.0, 0.0, 0.0) * S(0.8, 1.0, 0.8), (1.0, 1.0, 0.3), 0.0, 0.2, False, diffuse=0.8, **shiny),
+        cyl(T(1.0, 0.0, 0.0) * S(0.6, 1.0, 0.6), (1.0, 0.9, 0.4), 0.0, 0.3, False, diffuse=0.8, **shiny),
+        cyl(T(1.0, 0.0, 0.0) * S(0.4, 1.0, 0.4), (1.0, 0.8, 0.5), 0.0, 0.4, False, diffuse=0.8, **shiny),
+        cyl(T(1.0, 0.0, 0.0) * S(0.2, 1.0, 0.2), (1.0, 0.7, 0.6), 0.0, 0.5, True, diffuse=0.8, **shiny),
+        cyl(T(0.0, 0.0, -0.75) * S(0.05, 1.0, 0.05), (1.0, 0.0, 0.0), 0.0, 0.3, True, diffuse=0.9, **shiny),
+        cyl(T(0.0, 0.0, -2.25) * RY(-0.15) * T(0.0, 0.0, 1.5) * S(0.05, 1.0, 0.05), (1.0, 1.0, 0.0), 0.0, 0.3, True, diffuse=0.9, **shiny),
+        cyl(T(0.0, 0.0, -2.25) * RY(-0.3) * T(0.0, 0.0, 1.5) * S(0.05, 1.0, 0.05), (0.0, 1.0, 0.0), 0.0, 0.3, True, diffuse=0.9, **shiny),
+        cyl(T(0.0, 0.0, -2.25) * RY(-0.45) * T(0.0, 0.0, 1.5) * S(0.05, 1.0, 0.05), (0.0, 1.0, 1.0), 0.0, 0.3, True, diffuse=0.9, **shiny),
+        cyl(T(0.0, 0.0, -1.5) * S(0.33, 1.0, 0.33), (0.25, 0.0, 0.0), 0.0001, 0.5, True, diffuse=0.1, specular=0.9, shininess=300.0,
+            reflective=0.9, transparency=0.9, refractive_index=1.5),
+    ]
+    world = World([PointLight(Color.white(), Vector.point(1.0, 6.9, -4.9))], elements)
+    return _cam(4096, 2160, 0.314, (8.0, 3.5, -9.0), (0.0, 0.3, 0.0), (0.0, 1.0, 0.0), hsize, vsize), world
+
+
+def chapter14_title(hsize=None, vsize=None) -> Tuple[Camera, World]:
+    """src/bin/chapter14_title.rs:14-150 — three "wacky" objects: nested groups of spheres, open cylinders and open cones
+    (all-infinite reference boxes), group materials, four lights, a far backdrop plane."""
+    T, S, RX, RY, RZ = Matrix.translation, Matrix.scaling, Matrix.rotation_x, Matrix.rotation_y, Matrix.rotation_z
+
+    def leg(t):
+        sphere = Element.sphere(ShapeArgs(transform=T(0.0, 0.0, -1.0) * S(0.25, 0.25, 0.25)))
+        cylinder = Element.cylinder(ShapeArgs(transform=T(0.0, 0.0, -1.0) * RY(-0.5236) * RZ(-1.5708) * S(0.25, 1.0, 0.25)), 0.0, 1.0, False)
+        return Element.composite(t, None, GroupKind.Aggregation, [sphere, cylinder])
+
+    def cap(t):
+        cones = [Element.cone(ShapeArgs(transform=RY(PI / 3.0 * float(i)) * RX(-0.7854) * S(0.24606, 1.37002, 0.24606)), -1.0, 0.0, False) for i in range(6)]
+        return Element.composite(t, None, GroupKind.Aggregation, cones)
+
+    def wacky(t, material):
+        els = [leg(RY(PI / 3.0 * float(i))) for i in range(6)]
+        els.append(cap(T(0.0, 1.0, 0.0)))
+        els.append(cap(RX(PI) * T(0.0, 1.0, 0.0)))
+        return Element.composite(t, material, GroupKind.Aggregation, els)
+
+    mat = lambda r, g, b: Material(pattern=Pattern.plain(Color.new(r, g, b)), ambient=0.2, diffuse=0.8, specular=0.7, shininess=20.0)
+    elements = [
+        Element.plane(ShapeArgs(transform=T(0.0, 0.0, 100.0) * RX(1.5708), material=Material(pattern=Pattern.plain(Color.white()), ambient=1.0, diffuse=0.0, specular=0.0))),
+        wacky(T(-2.8, 0.0, 0.0) * RX(0.4363) * RY(0.1745), mat(0.9, 0.2, 0.4)),
+        wacky(RY(0.1745), mat(0.2, 0.9, 0.6)),
+        wacky(T(2.8, 0.0, 0.0) * RX(-0.4363) * RY(-0.1745), mat(0.2, 0.3, 1.0)),
+    ]
+    lights = [PointLight(Color.new(0.25, 0.25, 0.25), Vector.point(x, y, -10000.0)) for (x, y) in ((10000.0, 10000.0), (-10000.0, 10000.0), (10000.0, -10000.0), (-10000.0, -10000.0))]
+    return _cam(4096, 2160, 0.9, (0.0, 0.0, -9.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), hsize, vsize), World(lights, elements)
+
+
+def cover(hsize=None, vsize=None) -> Tuple[Camera, World]:
+    """src/bin/cover.rs:14-215 — the book cover: a glass sphere and 17 cubes in nested groups, two lights, tilted camera."""
+    T, S, RX = Matrix.translation, Matrix.scaling, Matrix.rotation_x
+    white = dict(diffuse=0.7, ambient=0.1, specular=0.0, reflective=0.1)
+    m_white = Material(pattern=Pattern.plain(Color.white()), **white)
+    m_blue = Material(pattern=Pattern.plain(Color.new(0.537, 0.831, 0.914)), **white)
+    m_red = Material(pattern=Pattern.plain(Color.new(0.941, 0.322, 0.388)), **white)
+    m_purple = Material(pattern=Pattern.plain(Color.new(0.373, 0.404, 0.550)), **white)
+    standard = S(0.5, 0.5, 0.5) * T(1.0, -1.0, 1.0)
+    large, medium, small = S(3.5, 3.5, 3.5) * standard, S(3.0, 3.0, 3.0) * standard, S(2.0, 2.0, 2.0) * standard
+    backdrop = Element.plane(ShapeArgs(transform=T(0.0, 0.0, 500.0) * RX(PI / 2.0), material=Material(pattern=Pattern.plain(Color.white()), ambient=1.0, diffuse=0.0, specular=0.0)))
+    sphere = Element.sphere(ShapeArgs(transform=large, material=Material(pattern=Pattern.plain(Color.new(0.373, 0.404, 0.550)), diffuse=0.2, ambient=0.0, specular=1.0,
+                                                                         shininess=200.0, reflective=0.7, transparency=0.7, refractive_index=1.5)))
+    cube = lambda t, m: Element.cube(ShapeArgs(transform=t, material=m))
+    top = [sphere,
+           cube(T(4.0, 0.0, 0.0) * medium, m_white), cube(T(8.5, 1.5, -0.5) * large, m_blue), cube(T(0.0, 0.0, 4.0) * large, m_red),
+           cube(T(4.0, 0.0, 4.0) * small, m_white), cube(T(7.5, 0.5, 4.0) * medium, m_purple), cube(T(-0.25, 0.25, 8.0) * medium, m_white),
+           cube(T(4.0, 1.0, 7.5) * large, m_blue), cube(T(10.0, 2.0, 7.5) * medium, m_red), cube(T(8.0, 2.0, 12.0) * small, m_white),
+           cube(T(20.0, 1.0, 9.0) * small, m_white)]
+    bot = [cube(T(-0.5, -5.0, 0.25) * large, m_blue), cube(T(4.0, -4.0, 0.0) * large, m_red), cube(T(8.5, -4.0, 0.0) * large, m_white),
+           cube(T(0.0, -4.0, 4.0) * large, m_white), cube(T(-0.5, -4.5, 8.0) * large, m_purple), cube(T(0.0, -8.0, 4.0) * large, m_white),
+           cube(T(-0.5, -8.5, 8.0) * large, m_white)]
+    group_all = Element.composite(Matrix.id(), None, GroupKind.Aggregation, [
+        Element.composite(Matrix.id(), None, GroupKind.Aggregation, top), Element.composite(Matrix.id(), None, GroupKind.Aggregation, bot)])
+    world = World([PointLight(Color.white(), Vector.point(50.0, 100.0, -50.0)), PointLight(Color.new(0.2, 0.2, 0.2), Vector.point(-400.0, 50.0, -10.0))],
+                  [backdrop, group_all])
+    return _cam(4096, 4096, 0.785, (-6.0, 6.0, -10.0), (6.0, 0.0, 6.0), (-0.45, 1.0, 0.0), hsize, vsize), world
+
+
 def chapter14_hexagon(hsize=None, vsize=None) -> Tuple[Camera, World]:
     """src/bin/chapter14_hexagon.rs:16-88 — nested groups of spheres + open cylinders, Simplex point-jitter."""
     def corner():

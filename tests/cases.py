@@ -180,6 +180,10 @@ SMALL_CASES = {
     "default_world": lambda: scenes.default_world(),
     "glass_air_bubble_200x100": lambda: scenes.chapter11_glass_air_bubble(200, 100),   # BASELINE config 1
     "chapter11_title": lambda: scenes.chapter11_title(96, 54),
+    "chapter12_title": lambda: scenes.chapter12_title(96, 54),
+    "chapter13_title": lambda: scenes.chapter13_title(96, 54),
+    "chapter14_title": lambda: scenes.chapter14_title(96, 54),
+    "cover": lambda: scenes.cover(64, 64),
     "chapter14_hexagon": lambda: scenes.chapter14_hexagon(96, 54),
     "chapter14_benchmark": lambda: scenes.chapter14_benchmark(96, 54),
     "teapot_low": lambda: scenes.chapter15_teapot("teapot_low.obj", 96, 54),

@@ -15,7 +15,9 @@ from PIL import Image
 
 REF = "/root/reference/image"
 OUT = os.path.dirname(os.path.abspath(__file__))
-IMAGES = ["chapter11_glass_air_bubble", "chapter11_title", "chapter14_benchmark", "chapter14_hexagon", "chapter15_teapot"]
+# new images are appended so that the per-image seeds (20241004 + index) of the existing fixtures do not change
+IMAGES = ["chapter11_glass_air_bubble", "chapter11_title", "chapter14_benchmark", "chapter14_hexagon", "chapter15_teapot",
+          "chapter12_title", "chapter13_title", "chapter14_title", "cover"]
 N = 1500
 M = 1000
 

@@ -20,6 +20,10 @@ SCENES = {
     "chapter14_benchmark": scenes.chapter14_benchmark,
     "chapter14_hexagon": scenes.chapter14_hexagon,
     "chapter15_teapot": scenes.chapter15_teapot,
+    "chapter12_title": scenes.chapter12_title,
+    "chapter13_title": scenes.chapter13_title,
+    "chapter14_title": scenes.chapter14_title,
+    "cover": scenes.cover,
 }
 
 
