@@ -43,6 +43,14 @@ def make_workload(name):
     elif name == "config3_high":
         cam, world = scenes.chapter15_teapot("teapot_high.obj", 1920, 1080)
         desc = "chapter15 teapot scene, teapot_high.obj (6320 smooth triangles) + BVH, 1920x1080, fuel 5"
+    elif name == "config4":
+        cam, world = scenes.chapter15_teapot("teapot_high.obj", 3840, 2160)
+        desc = "BASELINE configs[3] on this many GPUs: chapter15 teapot scene, teapot_high.obj (6320 smooth triangles) + BVH, 3840x2160, fuel 8"
+    elif name == "config5":
+        import tempfile
+        path = os.path.join(tempfile.gettempdir(), "rtc_heightfield_708x708_12345.obj")
+        cam, world = scenes.synthetic_mesh(path)   # writes the OBJ (999 698 triangles, one group) if it is not there yet
+        desc = "BASELINE configs[4] on this many GPUs: 999 698-triangle synthetic smooth mesh + Fractal/Simplex noise patterns, 3840x2160, fuel 8"
     else:
         raise SystemExit("unknown workload %r" % name)
     return cam, world, desc
@@ -100,11 +108,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="config2")
-    ap.add_argument("--fuel", type=int, default=5)
+    ap.add_argument("--fuel", type=int, default=None, help="recursion depth (default: 5; 8 for config4/config5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extra-workloads", default="config3", help="comma list measured (untimed region) and reported under 'extra' at N=1")
     args = ap.parse_args()
 
+    if args.fuel is None:
+        args.fuel = 8 if args.workload in ("config4", "config5") else 5
     import torch
     import raytracer_challenge_amd as rt
     from raytracer_challenge_amd.device import DeviceRenderer, algorithmic_bytes
@@ -185,7 +195,7 @@ def main():
         alg_bytes = algorithmic_bytes(cst)
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
         out = {
-            "metric": "Mrays/s (unique rays: primary+shadow+reflection+refraction) at 1920x1080 depth-5",
+            "metric": "Mrays/s (unique rays: primary+shadow+reflection+refraction) at %dx%d depth-%d" % (H, V, args.fuel),
             "value": rays_total * args.steps / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
