@@ -1,8 +1,11 @@
 // device_scene.h — layout of a flattened scene in HBM (shared by rtc_scene.cpp, which fills it, and
 // rtc_kernels.hip, which reads it).  Everything is SoA / fixed-size records, read-only during tracing.
 //
-// Traversal program ("ops"): the reference's Element tree (DFS pre-order) with every group's *bounded*
-// primitive children replaced by a results-neutral accelerator.  A ray walks the array once:
+// Traversal program ("ops").  The reference gates every primitive by the box tests of its ancestor groups
+// (Group::intersect, src/shape.rs:248-256) and otherwise tests all of them; the order of tests is irrelevant here because
+// ties are broken by key.  So aggregation groups are dissolved: every primitive carries `gcond` (its innermost group), the
+// gate is evaluated per primitive along group_parent with a per-ray cache, and ALL bounded primitives of the scene share
+// one accelerator per kind.  A ray walks the array once:
 //   OP_GROUP  a = group box index, b = pc to jump to when BoundingBox::intersects rejects the ray
 //   OP_PRIM   a = primitive index (exact test, own world->object matrix)
 //   (OP_MESH / OP_BVH: c = index of the BVH's frame in bvh_frame)
@@ -24,8 +27,10 @@
 
 enum { OP_PRIM = 0, OP_GROUP = 1, OP_MESH = 2, OP_BVH = 3, OP_QUIRK = 4, OP_QGRID = 5, OP_CSG = 6, OP_CSG_END = 7 };
 
-struct DOp {
+struct DOp {  // 32 bytes
   int32_t op, a, b, c;
+  int32_t g;       // OP_MESH / OP_CSG: innermost enclosing aggregation group (-1 = none) whose box chain gates the op
+  int32_t pad[3];
 };
 
 // 64-byte BVH2 node: both children's boxes (f32, rounded outward) + child refs.
@@ -60,7 +65,9 @@ struct DPrim {  // 32 bytes
   int32_t mat;
   int32_t xform;
   int32_t data;
-  int32_t pad[3];
+  int32_t gcond;   // innermost enclosing aggregation group outside any CSG (-1 = none): the primitive is tested only if the
+                   // reference's box test passes for that group and all its ancestors (group_parent chain)
+  int32_t pad[2];
 };
 
 struct DPat {  // pattern node, 192 bytes
@@ -75,6 +82,7 @@ struct DPat {  // pattern node, 192 bytes
 
 struct DScene {
   const DOp* ops;
+  const int32_t* group_parent;  // per group box index: enclosing aggregation group or -1 (boxes used by OP_GROUP/OP_CSG have -1)
   const double* group_box;   // n_groups x {lo[3], hi[3]} f64 exactly as the reference computed them
   const DBvhNode* bvh;
   const double* mtri;        // packed leaf-order triangles x {p1, e1, e2}

@@ -54,6 +54,8 @@ struct Trav {
   int shadowed;
   double c1_t, c2_t;
   int c1_prim, c2_prim;
+  // per-ray cache of the reference's group box tests (groups 0..63): bit set in g_known once evaluated, in g_pass if it hit
+  unsigned long long g_known, g_pass;
 };
 
 struct Counters {
@@ -101,6 +103,30 @@ __device__ __forceinline__ bool group_box_hit(const double* __restrict__ b, cons
   double t_min = rmax(rmax(xa, ya), za);
   double t_max = rmin(rmin(xb, yb), zb);
   return t_min <= t_max;
+}
+
+// Group::intersect's gate (src/shape.rs:251): a primitive (mesh, CSG node) under aggregation groups is reached only if
+// BoundingBox::intersects passes for every ancestor.  g = innermost group; walks group_parent; results cached per ray.
+__device__ __forceinline__ bool groups_pass(const DScene& S, int g, const Ray& r, Trav& T, Counters& C) {
+  while (g >= 0) {
+    bool hit;
+    if (g < 64) {
+      const unsigned long long bit = 1ull << g;
+      if (T.g_known & bit) hit = (T.g_pass & bit) != 0ull;
+      else {
+        C.group_tests++;
+        hit = group_box_hit(S.group_box + 6 * g, r);
+        T.g_known |= bit;
+        if (hit) T.g_pass |= bit;
+      }
+    } else {
+      C.group_tests++;
+      hit = group_box_hit(S.group_box + 6 * g, r);
+    }
+    if (!hit) return false;
+    g = S.group_parent[g];
+  }
+  return true;
 }
 
 // Ray::transform (src/ray.rs:14-19) with Matrix*Vector (src/linalg/matrix.rs:261-284); origin.w = 1, direction.w = 0.
@@ -264,6 +290,7 @@ __device__ __forceinline__ int prim_hits(const DScene& S, const DPrim& P, const 
 // the BVH leaf; all other rays are tested in the leaf only.  policy: 0 always, 1 skip if quirk, 2 only if quirk.
 __device__ __forceinline__ void visit_prim(const DScene& S, int prim, const Ray& r, Trav& T, Counters& C, int policy) {
   DPrim P = S.prims[prim];
+  if (P.gcond >= 0 && !groups_pass(S, P.gcond, r, T, C)) return;
   const double* __restrict__ m = S.xf_inv + 12 * P.xform;
   if (P.geom == 1) {
     // Plane (src/shape.rs:621-633) only reads origin.y and direction.y of the object-space ray: evaluate that one row of
@@ -503,10 +530,13 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
       C.group_tests++;
       pc = group_box_hit(S.group_box + 6 * op.a, r) ? pc + 1 : op.b;
     } else if (CSGK && op.op == OP_CSG) {
-      pc = csg_eval(S, pc, r, T, C);
+      if (op.g >= 0 && !groups_pass(S, op.g, r, T, C)) pc = op.b + 1;
+      else pc = csg_eval(S, pc, r, T, C);
     } else if (op.op == OP_MESH) {
-      Ray o = to_object(S.xf_inv + 12 * op.b, r);
-      bvh_walk<true>(S, op.a, op.c, r, o, T, C, stack, stride);
+      if (op.g < 0 || groups_pass(S, op.g, r, T, C)) {
+        Ray o = to_object(S.xf_inv + 12 * op.b, r);
+        bvh_walk<true>(S, op.a, op.c, r, o, T, C, stack, stride);
+      }
       pc++;
     } else {
       bvh_walk<false>(S, op.a, op.c, r, r, T, C, stack, stride);
@@ -801,6 +831,7 @@ __device__ __forceinline__ void reset_closest(Trav& T, int mode) {
   T.best_t = DINF; T.best_prim = 0x7fffffff; T.best_k = 0; T.best_klast = 0;
   T.shadowed = 0;
   T.c1_t = 0.0; T.c2_t = 0.0; T.c1_prim = -1; T.c2_prim = -1;
+  T.g_known = 0ull; T.g_pass = 0ull;
 }
 
 // u, v of the winning triangle: the traversal does not carry them; the same test on the same numbers gives the same bits.
@@ -1214,6 +1245,8 @@ __device__ __forceinline__ void step_op(const DScene& S, Lane& L, Counters& C, c
   } else if (op.op == OP_GROUP) {
     C.group_tests++;
     L.pc = group_box_hit(S.group_box + 6 * op.a, L.r) ? L.pc + 1 : op.b;
+  } else if (op.op == OP_MESH && op.g >= 0 && !groups_pass(S, op.g, L.r, L.T, C)) {
+    L.pc++;
   } else if (op.op == OP_MESH || op.op == OP_BVH) {
     if (op.op == OP_MESH) { L.r = to_object(S.xf_inv + 12 * op.b, L.r); L.in_mesh = 1; }
     make_frame(S.bvh_frame + 4 * op.c, L.r, L.F);

@@ -213,7 +213,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     int rc_ = s->upload(H.field, &d.field);                             \
     if (rc_ != RTC_OK) { rtc_scene_destroy(s.release()); return rc_; } \
   } while (0)
-  UP(ops); UP(group_box); UP(bvh); UP(mtri); UP(mtri_prim); {
+  UP(ops); UP(group_box); UP(group_parent); UP(bvh); UP(mtri); UP(mtri_prim); {
     int rc_ = s->upload(H.items, &d.item_prim);
     if (rc_ != RTC_OK) { rtc_scene_destroy(s.release()); return rc_; }
     d.quirk_prim = d.item_prim;

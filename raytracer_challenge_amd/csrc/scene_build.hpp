@@ -217,14 +217,15 @@ struct ProgramBuilder {
       const rtc_node& n = D.nodes[i];
       if (n.skip <= (int32_t)i || (uint32_t)n.skip > e) { error = "node skip out of range"; status = RTC_ERR_INVALID; return false; }
       if (n.kind == RTC_NODE_PRIM) {
-        ops.push_back({OP_PRIM, n.ref, 0, 0});
+        ops.push_back({OP_PRIM, n.ref, 0, 0, -1, {0, 0, 0}});
         *hits += max_hits(D.prims[n.ref].geometry);
       } else if (n.kind == RTC_NODE_AGGREGATION) {
         int32_t gi = (int32_t)(group_box.size() / 6);
         group_box.insert(group_box.end(), n.bbox_min, n.bbox_min + 3);
         group_box.insert(group_box.end(), n.bbox_max, n.bbox_max + 3);
+        group_parent.push_back(-1);
         size_t at = ops.size();
-        ops.push_back({OP_GROUP, gi, 0, 0});
+        ops.push_back({OP_GROUP, gi, 0, 0, -1, {0, 0, 0}});
         if (!emit_linear(i + 1, (uint32_t)n.skip, depth, hits)) return false;
         ops[at].b = (int32_t)ops.size();
       } else {
@@ -236,7 +237,7 @@ struct ProgramBuilder {
   }
 
   // A Union / Intersection / Difference group (src/shape.rs:74-101 asserts exactly two children).
-  bool emit_csg(uint32_t i, int depth, int* outer_hits = nullptr) {
+  bool emit_csg(uint32_t i, int depth, int* outer_hits = nullptr, int32_t gate = -1) {
     const rtc_node& n = D.nodes[i];
     if (depth >= RTC_CSG_MAX_DEPTH) { error = "CSG groups nested deeper than RTC_CSG_MAX_DEPTH"; status = RTC_ERR_UNSUPPORTED; return false; }
     // children: first child = node i+1, second = the node after the first child's subtree
@@ -257,11 +258,12 @@ struct ProgramBuilder {
     group_box.insert(group_box.end(), n.bbox_min, n.bbox_min + 3);
     group_box.insert(group_box.end(), n.bbox_max, n.bbox_max + 3);
     size_t at = ops.size();
-    ops.push_back({OP_CSG, gi, 0, ci});
+    group_parent.push_back(-1);
+    ops.push_back({OP_CSG, gi, 0, ci, gate, {0, 0, 0}});
     int hits = 0;
     if (!emit_linear(c0, end, depth, &hits)) return false;
     ops[at].b = (int32_t)ops.size();
-    ops.push_back({OP_CSG_END, 0, 0, ci});
+    ops.push_back({OP_CSG_END, 0, 0, ci, -1, {0, 0, 0}});
     if (hits > RTC_CSG_MAX_HITS) {
       error = "a CSG group's subtree can produce more than RTC_CSG_MAX_HITS intersections (device buffer)";
       status = RTC_ERR_UNSUPPORTED;
@@ -271,21 +273,44 @@ struct ProgramBuilder {
     return true;
   }
 
-  // Emits the program for the children list nodes[b, e) of one group (or of the world).
-  bool emit(uint32_t b, uint32_t e) {
-    std::vector<uint32_t> prim_kids, group_kids;
+  // ---- whole-scene emission: aggregation groups are dissolved into per-primitive gates -------------------------------------
+  std::vector<int32_t> prim_gcond;   // per primitive
+  std::vector<int32_t> group_parent; // per group box index
+  struct PendingCsg { uint32_t node; int32_t g; };
+  std::vector<PendingCsg> pending_csg;
+  std::vector<int32_t> top_prims;    // primitives outside any CSG, in DFS order
+
+  bool collect(uint32_t b, uint32_t e, int32_t g) {
     for (uint32_t i = b; i < e;) {
       const rtc_node& n = D.nodes[i];
       if (n.skip <= (int32_t)i || (uint32_t)n.skip > e) { error = "node skip out of range"; status = RTC_ERR_INVALID; return false; }
-      if (n.kind == RTC_NODE_PRIM) prim_kids.push_back(i); else group_kids.push_back(i);
+      if (n.kind == RTC_NODE_PRIM) {
+        prim_gcond[n.ref] = g;
+        top_prims.push_back(n.ref);
+      } else if (n.kind == RTC_NODE_AGGREGATION) {
+        int32_t gi = (int32_t)(group_box.size() / 6);
+        group_box.insert(group_box.end(), n.bbox_min, n.bbox_min + 3);
+        group_box.insert(group_box.end(), n.bbox_max, n.bbox_max + 3);
+        group_parent.push_back(g);
+        if (!collect(i + 1, (uint32_t)n.skip, gi)) return false;
+      } else {
+        pending_csg.push_back({i, g});
+      }
       i = (uint32_t)n.skip;
     }
-    // 1. triangles that share one matrix -> object-space mesh BVHs
-    std::map<int32_t, std::vector<int32_t>> meshes;
+    return true;
+  }
+
+  // Emits the program for the whole world.
+  bool emit(uint32_t b, uint32_t e) {
+    prim_gcond.assign(D.n_prims, -1);
+    if (!collect(b, e, -1)) return false;
+    // 1. triangles that share one matrix AND one gate -> object-space mesh BVHs
+    std::map<std::pair<int32_t, int32_t>, std::vector<int32_t>> meshes;
     std::vector<int32_t> rest;
-    for (uint32_t i : prim_kids) {
-      const rtc_prim& p = D.prims[D.nodes[i].ref];
-      if (p.geometry >= RTC_TRIANGLE) meshes[p.xform].push_back(D.nodes[i].ref); else rest.push_back(D.nodes[i].ref);
+    for (int32_t pi : top_prims) {
+      const rtc_prim& p = D.prims[pi];
+      if (p.geometry >= RTC_TRIANGLE) meshes[{p.xform, prim_gcond[pi]}].push_back(pi); else rest.push_back(pi);
     }
     for (auto& kv : meshes) {
       std::vector<bvh::Item> items;
@@ -302,13 +327,13 @@ struct ProgramBuilder {
       int32_t root = build_tree(items, order, base, true, &fi);
       for (uint32_t k : order) {
         int32_t pi = ids[k];
-        const double* g = D.tri_p1e1e2 + 9 * (size_t)D.prims[pi].data;
-        mtri.insert(mtri.end(), g, g + 9);
+        const double* gq = D.tri_p1e1e2 + 9 * (size_t)D.prims[pi].data;
+        mtri.insert(mtri.end(), gq, gq + 9);
         mtri_prim.push_back(pi);
       }
-      ops.push_back({OP_MESH, root, kv.first, fi});
+      ops.push_back({OP_MESH, root, kv.first.first, fi, kv.first.second, {0, 0, 0}});
     }
-    // 2. remaining bounded primitives -> one world-space BVH; unbounded ones stay linear
+    // 2. every other bounded primitive of the scene -> ONE world-space BVH; unbounded ones stay linear
     {
       std::vector<bvh::Item> items;
       std::vector<int32_t> ids, linear;
@@ -318,37 +343,25 @@ struct ProgramBuilder {
       }
       if (items.size() < kMinAccel) { for (int32_t pi : ids) linear.push_back(pi); ids.clear(); items.clear(); }
       std::sort(linear.begin(), linear.end());
-      for (int32_t pi : linear) ops.push_back({OP_PRIM, pi, 0, 0});
+      for (int32_t pi : linear) ops.push_back({OP_PRIM, pi, 0, 0, -1, {0, 0, 0}});
       if (!items.empty()) {
         std::vector<uint32_t> order;
         uint32_t base = (uint32_t)item_prim.size();
         int32_t fi = 0;
         int32_t root = build_tree(items, order, base, false, &fi);
         for (uint32_t k : order) item_prim.push_back(ids[k]);
-        ops.push_back({OP_BVH, root, 0, fi});
+        ops.push_back({OP_BVH, root, 0, fi, -1, {0, 0, 0}});
         int32_t q0 = (int32_t)quirk_prim.size();
         for (int32_t pi : ids)
           if (D.prims[pi].geometry == RTC_CUBE || D.prims[pi].geometry == RTC_CONE) quirk_prim.push_back(pi);
         int32_t qn = (int32_t)quirk_prim.size() - q0;
-        if (qn >= kMinQuirkGrid) ops.push_back({OP_QGRID, build_quirk_grid(q0, qn), 0, 0});
-        else if (qn > 0) ops.push_back({OP_QUIRK, q0, qn, 0});
+        if (qn >= kMinQuirkGrid) ops.push_back({OP_QGRID, build_quirk_grid(q0, qn), 0, 0, -1, {0, 0, 0}});
+        else if (qn > 0) ops.push_back({OP_QUIRK, q0, qn, 0, -1, {0, 0, 0}});
       }
     }
-    // 3. child groups: exact reference box test, then their own program
-    for (uint32_t i : group_kids) {
-      const rtc_node& n = D.nodes[i];
-      if (n.kind != RTC_NODE_AGGREGATION) {
-        if (!emit_csg(i, 0)) return false;
-        continue;
-      }
-      int32_t gi = (int32_t)(group_box.size() / 6);
-      group_box.insert(group_box.end(), n.bbox_min, n.bbox_min + 3);
-      group_box.insert(group_box.end(), n.bbox_max, n.bbox_max + 3);
-      size_t at = ops.size();
-      ops.push_back({OP_GROUP, gi, 0, 0});
-      if (!emit(i + 1, (uint32_t)n.skip)) return false;
-      ops[at].b = (int32_t)ops.size();
-    }
+    // 3. CSG groups: linear sub-programs, gated by their enclosing aggregation groups
+    for (const PendingCsg& c : pending_csg)
+      if (!emit_csg(c.node, 0, nullptr, c.g)) return false;
     return true;
   }
 };
@@ -407,6 +420,7 @@ inline int validate(const rtc_scene_desc& D, std::string* err) {
 struct HostArrays {
   std::vector<DOp> ops;
   std::vector<double> group_box;
+  std::vector<int32_t> group_parent;
   std::vector<DBvhNode> bvh;
   std::vector<double> mtri;
   std::vector<int32_t> mtri_prim, items;  // items: BVH leaf items + quirk lists + grid cells, absolute indices
@@ -423,7 +437,7 @@ struct HostArrays {
 
   DScene view() const {
     DScene d{};
-    d.ops = ops.data(); d.group_box = group_box.data(); d.bvh = bvh.data(); d.mtri = mtri.data(); d.mtri_prim = mtri_prim.data();
+    d.ops = ops.data(); d.group_box = group_box.data(); d.group_parent = group_parent.data(); d.bvh = bvh.data(); d.mtri = mtri.data(); d.mtri_prim = mtri_prim.data();
     d.item_prim = items.data(); d.quirk_prim = items.data(); d.qgrids = qgrids.data(); d.qcell = qcell.data(); d.bvh_frame = bvh_frame.data(); d.csg = csg.data(); d.qitem = items.data(); d.prims = prims.data(); d.xf_inv = xf_inv.data(); d.xf_matinv = xf_matinv.data(); d.limits = limits.data();
     d.tri_geo = tri_geo.data(); d.tri_nrm = tri_nrm.data(); d.mat = mat.data(); d.mat_pattern = mat_pattern.data(); d.pats = pats.data();
     d.lights = lights.data();
@@ -447,7 +461,7 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
   H->prims.resize(D.n_prims);
   H->all_cast_shadow = 1;
   for (uint32_t i = 0; i < D.n_prims; i++) {
-    H->prims[i] = {D.prims[i].geometry, D.prims[i].flags, D.prims[i].material, D.prims[i].xform, D.prims[i].data, {0, 0, 0}};
+    H->prims[i] = {D.prims[i].geometry, D.prims[i].flags, D.prims[i].material, D.prims[i].xform, D.prims[i].data, pb.prim_gcond.empty() ? -1 : pb.prim_gcond[i], {0, 0}};
     if (!(D.prims[i].flags & RTC_FLAG_CASTS_SHADOW)) H->all_cast_shadow = 0;
   }
   H->xf_inv.resize((size_t)D.n_xforms * 12);
@@ -483,11 +497,13 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
   }
   H->n_lights = (int32_t)D.n_lights;
   if (pb.ops.empty()) {  // empty world: one group whose rejected branch ends the program
-    pb.ops.push_back({OP_GROUP, 0, 1, 0});
+    pb.ops.push_back({OP_GROUP, 0, 1, 0, -1, {0, 0, 0}});
     pb.group_box.insert(pb.group_box.end(), {1, 1, 1, 0, 0, 0});
+    pb.group_parent.push_back(-1);
   }
   H->ops = std::move(pb.ops);
   H->group_box = std::move(pb.group_box);
+  H->group_parent = std::move(pb.group_parent);
   H->bvh = std::move(pb.bvh_nodes);
   H->mtri = std::move(pb.mtri);
   H->mtri_prim = std::move(pb.mtri_prim);
