@@ -288,9 +288,12 @@ __device__ __forceinline__ int prim_hits(const DScene& S, const DPrim& P, const 
 //   cone: when a ~ 0 the single root -c/(2b) is pushed without the min < y < max check (src/shape.rs:812-818).
 // Rays in that state ("quirk rays" for this primitive) are tested by the linear OP_QUIRK pass and skipped in
 // the BVH leaf; all other rays are tested in the leaf only.  policy: 0 always, 1 skip if quirk, 2 only if quirk.
+// FEAT: feature level of the kernel instantiation — 0: no groups, no CSG in the scene (no gate code at all),
+// 1: aggregation-group gates, 2: gates + CSG.  Keeps the common kernel under the register cliff.
+template <int FEAT>
 __device__ __forceinline__ void visit_prim(const DScene& S, int prim, const Ray& r, Trav& T, Counters& C, int policy) {
   DPrim P = S.prims[prim];
-  if (P.gcond >= 0 && !groups_pass(S, P.gcond, r, T, C)) return;
+  if (FEAT >= 1 && P.gcond >= 0 && !groups_pass(S, P.gcond, r, T, C)) return;
   const double* __restrict__ m = S.xf_inv + 12 * P.xform;
   if (P.geom == 1) {
     // Plane (src/shape.rs:621-633) only reads origin.y and direction.y of the object-space ray: evaluate that one row of
@@ -327,11 +330,12 @@ __device__ __forceinline__ void visit_prim(const DScene& S, int prim, const Ray&
 }
 
 // Direction-grid culled quirk scan (device_scene.h OP_QGRID).  The cell lookup must mirror build_quirk_grid().
+template <int FEAT>
 __device__ __forceinline__ void quirk_grid_scan(const DScene& S, const DQuirkGrid G, const Ray& r, Trav& T, Counters& C) {
   double ax = fabs(r.dx), ay = fabs(r.dy), az = fabs(r.dz);
   double len2 = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
   if (!(len2 >= RTC_QGRID_MIN_LEN * RTC_QGRID_MIN_LEN) || !(len2 < DINF)) {
-    for (int i = G.lin_first; i < G.lin_first + G.lin_count; i++) visit_prim(S, S.quirk_prim[i], r, T, C, 2);
+    for (int i = G.lin_first; i < G.lin_first + G.lin_count; i++) visit_prim<FEAT>(S, S.quirk_prim[i], r, T, C, 2);
     return;
   }
   int face;
@@ -344,7 +348,7 @@ __device__ __forceinline__ void quirk_grid_scan(const DScene& S, const DQuirkGri
   iv = iv < 0 ? 0 : (iv >= G.n ? G.n - 1 : iv);
   int cell = G.cell_off + (face * G.n + iv) * G.n + iu;
   unsigned b = S.qcell[cell], e = S.qcell[cell + 1];
-  for (unsigned i = b; i < e; i++) visit_prim(S, S.qitem[i], r, T, C, 2);
+  for (unsigned i = b; i < e; i++) visit_prim<FEAT>(S, S.qitem[i], r, T, C, 2);
 }
 
 // ---- accelerator -------------------------------------------------------------------------------------
@@ -390,7 +394,7 @@ __device__ __forceinline__ bool slab32(const float* __restrict__ lo, const float
   return fmaxf(tn, tlo) <= fminf(tf, thi) && lo[0] <= hi[0];
 }
 
-template <bool MESH>
+template <bool MESH, int FEAT>
 __device__ __forceinline__ void bvh_walk(const DScene& S, int root, int frame, const Ray& world, const Ray& o, Trav& T, Counters& C, int* __restrict__ stack, int stride) {
   Frame32 F;
   make_frame(S.bvh_frame + 4 * frame, o, F);
@@ -424,7 +428,7 @@ __device__ __forceinline__ void bvh_walk(const DScene& S, int root, int frame, c
           C.tri_tests++;
           if (tri_hit(S.mtri + 9 * (size_t)i, o, t, u, v)) accept(T, C, S.mtri_prim[i], 1, &t);
         } else {
-          visit_prim(S, S.item_prim[i], world, T, C, 1);
+          visit_prim<FEAT>(S, S.item_prim[i], world, T, C, 1);
         }
       }
       if (T.mode == MODE_SHADOW_ANY && T.shadowed) return;
@@ -510,7 +514,7 @@ __device__ __noinline__ int csg_eval(const DScene& S, int pc, const Ray& r, Trav
 
 // World::intersect (src/world.rs:18-24) + Group::intersect (src/shape.rs:248-269) over the flattened program.
 // CSGK: the kernel instantiation for scenes that contain CSG groups; all others never see the (register-hungry) call.
-template <bool CSGK>
+template <int FEAT>
 __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T, Counters& C, int* __restrict__ stack, int stride) {
   int pc = 0;
   const int n = S.n_ops;
@@ -518,28 +522,28 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
     DIAG_LOOP(2);
     DOp op = S.ops[pc];
     if (op.op == OP_PRIM) {
-      visit_prim(S, op.a, r, T, C, 0);
+      visit_prim<FEAT>(S, op.a, r, T, C, 0);
       pc++;
     } else if (op.op == OP_QUIRK) {
-      for (int i = op.a; i < op.a + op.b; i++) visit_prim(S, S.quirk_prim[i], r, T, C, 2);
+      for (int i = op.a; i < op.a + op.b; i++) visit_prim<FEAT>(S, S.quirk_prim[i], r, T, C, 2);
       pc++;
     } else if (op.op == OP_QGRID) {
-      quirk_grid_scan(S, S.qgrids[op.a], r, T, C);
+      quirk_grid_scan<FEAT>(S, S.qgrids[op.a], r, T, C);
       pc++;
     } else if (op.op == OP_GROUP) {
       C.group_tests++;
       pc = group_box_hit(S.group_box + 6 * op.a, r) ? pc + 1 : op.b;
-    } else if (CSGK && op.op == OP_CSG) {
+    } else if (FEAT >= 2 && op.op == OP_CSG) {
       if (op.g >= 0 && !groups_pass(S, op.g, r, T, C)) pc = op.b + 1;
       else pc = csg_eval(S, pc, r, T, C);
     } else if (op.op == OP_MESH) {
-      if (op.g < 0 || groups_pass(S, op.g, r, T, C)) {
+      if (FEAT == 0 || op.g < 0 || groups_pass(S, op.g, r, T, C)) {
         Ray o = to_object(S.xf_inv + 12 * op.b, r);
-        bvh_walk<true>(S, op.a, op.c, r, o, T, C, stack, stride);
+        bvh_walk<true, FEAT>(S, op.a, op.c, r, o, T, C, stack, stride);
       }
       pc++;
     } else {
-      bvh_walk<false>(S, op.a, op.c, r, r, T, C, stack, stride);
+      bvh_walk<false, FEAT>(S, op.a, op.c, r, r, T, C, stack, stride);
       pc++;
     }
     if (T.mode == MODE_SHADOW_ANY && T.shadowed) return;
@@ -920,8 +924,8 @@ __device__ __forceinline__ Ray slot_ray(const DPixelMap& pm, const DCamera& cam,
 // REFILL = true  (v3): a lane that finishes its pixel immediately takes the next work id from a global counter and
 //   keeps iterating the same ray loop, so the wave's lanes stay busy until the frame runs out (persistent waves,
 //   refill at ray granularity); the grid is sized to the resident wave count.
-template <bool COUNT, bool REFILL, bool CSGK>
-__global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD) rtc_trace_kernel(DScene S, DCamera cam, DPixelMap pm, int fuel0, double* __restrict__ rgb, double* __restrict__ hit_t,
+template <bool COUNT, bool REFILL, int FEAT>
+__global__ void __launch_bounds__(RTC_BLOCK, (FEAT >= 1 && RTC_WAVES_PER_SIMD < 2) ? 2 : RTC_WAVES_PER_SIMD) rtc_trace_kernel(DScene S, DCamera cam, DPixelMap pm, int fuel0, double* __restrict__ rgb, double* __restrict__ hit_t,
                                                         int* __restrict__ hit_prim, int* __restrict__ hit_k, DStats* __restrict__ stats,
                                                         unsigned long long* __restrict__ next_work) {
   __shared__ int lds_stack[RTC_BVH_STACK * RTC_BLOCK];
@@ -964,7 +968,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD) rtc_trace_kerne
       DIAG_T0();
       Trav T;
       reset_closest(T, MODE_CLOSEST);
-      traverse<CSGK>(S, ray, T, C, stack, stride);
+      traverse<FEAT>(S, ray, T, C, stack, stride);
       DIAG_REGION(0);
       bool did_hit = T.best_prim != 0x7fffffff;
       if (first) {
@@ -992,7 +996,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD) rtc_trace_kerne
           K.mode = MODE_CONTAINERS;
           K.tlo = -DINF; K.thi = T.best_t;
           K.c1_prim = -1; K.c2_prim = -1; K.c1_t = 0.0; K.c2_t = 0.0;
-          traverse<CSGK>(S, ray, K, C, stack, stride);
+          traverse<FEAT>(S, ray, K, C, stack, stride);
           if (K.c1_prim >= 0) n1 = S.mat[8 * S.prims[K.c1_prim].mat + 6];
           if (K.c2_prim >= 0) n2 = S.mat[8 * S.prims[K.c2_prim].mat + 6];
           DIAG_REGION(1);
@@ -1027,7 +1031,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD) rtc_trace_kerne
           reset_closest(Sh, S.all_cast_shadow ? MODE_SHADOW_ANY : MODE_SHADOW_CLOSEST);
           if (S.all_cast_shadow) Sh.thi = distance;
           DIAG_T0();
-          traverse<CSGK>(S, sray, Sh, C, stack, stride);
+          traverse<FEAT>(S, sray, Sh, C, stack, stride);
           DIAG_REGION(3);
           bool shadowed;
           if (S.all_cast_shadow) shadowed = Sh.shadowed != 0;
@@ -1312,7 +1316,7 @@ __device__ __forceinline__ void step_prim(const DScene& S, Lane& L, Counters& C,
   policy = direct ? 0 : (L.it_kind == IT_BVHITEM ? 1 : 2);
   L.it++;
   if ((unsigned)prim >= (unsigned)S.n_prims) { L.it--; guard_trip(L, S, gmask, G_PRIM, prim); return; }
-  visit_prim(S, prim, L.r, L.T, C, policy);
+  visit_prim<1>(S, prim, L.r, L.T, C, policy);
 }
 __device__ __forceinline__ void step_tri(const DScene& S, Lane& L, Counters& C, unsigned& gmask) {
   double t, u, v;
@@ -1665,17 +1669,18 @@ void rtc_launch_quantize(const double* rgb, unsigned char* out, unsigned long lo
 }
 
 template <bool COUNT, bool REFILL>
-static void launch_trace_t(bool csg, dim3 grid, dim3 block, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb,
+static void launch_trace_t(int feat, dim3 grid, dim3 block, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb,
                            double* hit_t, int* hit_prim, int* hit_k, DStats* stats, unsigned long long* next_work) {
-  if (csg) hipLaunchKernelGGL((rtc_trace_kernel<COUNT, REFILL, true>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
-  else hipLaunchKernelGGL((rtc_trace_kernel<COUNT, REFILL, false>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
+  if (feat >= 2) hipLaunchKernelGGL((rtc_trace_kernel<COUNT, REFILL, 2>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
+  else if (feat == 1) hipLaunchKernelGGL((rtc_trace_kernel<COUNT, REFILL, 1>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
+  else hipLaunchKernelGGL((rtc_trace_kernel<COUNT, REFILL, 0>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
 }
 
 void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
                       DStats* stats, bool count, hipStream_t stream, unsigned refill_blocks, unsigned long long* next_work) {
   if (pm.n == 0) return;
   dim3 block(RTC_BLOCK);
-  const bool csg = S.has_csg != 0;
+  const int csg = S.has_csg ? 2 : (S.has_groups ? 1 : 0);  // feature level of the kernel instantiation
   if (refill_blocks) {  // v3: persistent grid; next_work was set to refill_blocks * RTC_BLOCK by the caller
     dim3 grid(refill_blocks);
     if (count) launch_trace_t<true, true>(csg, grid, block, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
@@ -1693,7 +1698,7 @@ void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, 
 #ifndef RTC_EMU
 int rtc_v3_blocks_per_cu(void) {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtc_trace_kernel<false, true, false>, RTC_BLOCK, 0) != hipSuccess || nb <= 0) nb = 4;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtc_trace_kernel<false, true, 0>, RTC_BLOCK, 0) != hipSuccess || nb <= 0) nb = 4;
   return nb;
 }
 #endif

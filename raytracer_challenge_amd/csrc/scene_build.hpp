@@ -446,6 +446,9 @@ struct HostArrays {
     d.n_qitem = (int32_t)items.size(); d.n_qcell = (int32_t)qcell.size(); d.n_groups = (int32_t)(group_box.size() / 6); d.n_qgrids = (int32_t)qgrids.size();
     d.has_mesh = 0;
     d.has_csg = 0;
+    d.has_groups = 0;
+    for (const DPrim& q : prims) if (q.gcond >= 0) d.has_groups = 1;
+    for (const DOp& o : ops) if (o.g >= 0) d.has_groups = 1;
     for (const DOp& o : ops) { if (o.op == OP_MESH) d.has_mesh = 1; if (o.op == OP_CSG) d.has_csg = 1; }
     return d;
   }
