@@ -108,7 +108,7 @@ struct DScene {
   int32_t all_cast_shadow;   // 1: every primitive casts a shadow -> shadow rays may stop at any hit
   int32_t has_mesh;          // 1: the program contains an OP_MESH
   int32_t has_csg;           // 1: the program contains an OP_CSG
-  int32_t has_groups;        // 1: some primitive / mesh / CSG node is gated by an aggregation group
+  int32_t has_groups;        // 0: no gates; 1: only OP_MESH / OP_CSG ops are gated; 2: individual primitives are gated
   // array lengths, for the traversal guards (a bad index retires the lane and raises DStats.guard instead of faulting)
   int32_t n_bvh, n_items, n_mtri, n_quirk, n_qitem, n_qcell, n_groups, n_qgrids;
 };

@@ -107,10 +107,11 @@ __device__ __forceinline__ bool group_box_hit(const double* __restrict__ b, cons
 
 // Group::intersect's gate (src/shape.rs:251): a primitive (mesh, CSG node) under aggregation groups is reached only if
 // BoundingBox::intersects passes for every ancestor.  g = innermost group; walks group_parent; results cached per ray.
+template <bool CACHE = true>
 __device__ __forceinline__ bool groups_pass(const DScene& S, int g, const Ray& r, Trav& T, Counters& C) {
   while (g >= 0) {
     bool hit;
-    if (g < 64) {
+    if (CACHE && g < 64) {
       const unsigned long long bit = 1ull << g;
       if (T.g_known & bit) hit = (T.g_pass & bit) != 0ull;
       else {
@@ -288,12 +289,13 @@ __device__ __forceinline__ int prim_hits(const DScene& S, const DPrim& P, const 
 //   cone: when a ~ 0 the single root -c/(2b) is pushed without the min < y < max check (src/shape.rs:812-818).
 // Rays in that state ("quirk rays" for this primitive) are tested by the linear OP_QUIRK pass and skipped in
 // the BVH leaf; all other rays are tested in the leaf only.  policy: 0 always, 1 skip if quirk, 2 only if quirk.
-// FEAT: feature level of the kernel instantiation — 0: no groups, no CSG in the scene (no gate code at all),
-// 1: aggregation-group gates, 2: gates + CSG.  Keeps the common kernel under the register cliff.
+// FEAT: feature level of the kernel instantiation — 0: no groups, no CSG in the scene (no gate code at all); 1: only whole
+// meshes are gated (one uncached chain walk per OP_MESH: the teapot scenes); 2: per-primitive gates with the per-ray cache;
+// 3: + CSG.  Keeps the common kernels under the register cliff.
 template <int FEAT>
 __device__ __forceinline__ void visit_prim(const DScene& S, int prim, const Ray& r, Trav& T, Counters& C, int policy) {
   DPrim P = S.prims[prim];
-  if (FEAT >= 1 && P.gcond >= 0 && !groups_pass(S, P.gcond, r, T, C)) return;
+  if (FEAT >= 2 && P.gcond >= 0 && !groups_pass(S, P.gcond, r, T, C)) return;
   const double* __restrict__ m = S.xf_inv + 12 * P.xform;
   if (P.geom == 1) {
     // Plane (src/shape.rs:621-633) only reads origin.y and direction.y of the object-space ray: evaluate that one row of
@@ -533,11 +535,11 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
     } else if (op.op == OP_GROUP) {
       C.group_tests++;
       pc = group_box_hit(S.group_box + 6 * op.a, r) ? pc + 1 : op.b;
-    } else if (FEAT >= 2 && op.op == OP_CSG) {
+    } else if (FEAT >= 3 && op.op == OP_CSG) {
       if (op.g >= 0 && !groups_pass(S, op.g, r, T, C)) pc = op.b + 1;
       else pc = csg_eval(S, pc, r, T, C);
     } else if (op.op == OP_MESH) {
-      if (FEAT == 0 || op.g < 0 || groups_pass(S, op.g, r, T, C)) {
+      if (FEAT == 0 || op.g < 0 || groups_pass<(FEAT >= 2)>(S, op.g, r, T, C)) {
         Ray o = to_object(S.xf_inv + 12 * op.b, r);
         bvh_walk<true, FEAT>(S, op.a, op.c, r, o, T, C, stack, stride);
       }
@@ -925,7 +927,7 @@ __device__ __forceinline__ Ray slot_ray(const DPixelMap& pm, const DCamera& cam,
 //   keeps iterating the same ray loop, so the wave's lanes stay busy until the frame runs out (persistent waves,
 //   refill at ray granularity); the grid is sized to the resident wave count.
 template <bool COUNT, bool REFILL, int FEAT>
-__global__ void __launch_bounds__(RTC_BLOCK, (FEAT >= 1 && RTC_WAVES_PER_SIMD < 2) ? 2 : RTC_WAVES_PER_SIMD) rtc_trace_kernel(DScene S, DCamera cam, DPixelMap pm, int fuel0, double* __restrict__ rgb, double* __restrict__ hit_t,
+__global__ void __launch_bounds__(RTC_BLOCK, (FEAT >= 2 && RTC_WAVES_PER_SIMD < 2) ? 2 : RTC_WAVES_PER_SIMD) rtc_trace_kernel(DScene S, DCamera cam, DPixelMap pm, int fuel0, double* __restrict__ rgb, double* __restrict__ hit_t,
                                                         int* __restrict__ hit_prim, int* __restrict__ hit_k, DStats* __restrict__ stats,
                                                         unsigned long long* __restrict__ next_work) {
   __shared__ int lds_stack[RTC_BVH_STACK * RTC_BLOCK];
@@ -1316,7 +1318,7 @@ __device__ __forceinline__ void step_prim(const DScene& S, Lane& L, Counters& C,
   policy = direct ? 0 : (L.it_kind == IT_BVHITEM ? 1 : 2);
   L.it++;
   if ((unsigned)prim >= (unsigned)S.n_prims) { L.it--; guard_trip(L, S, gmask, G_PRIM, prim); return; }
-  visit_prim<1>(S, prim, L.r, L.T, C, policy);
+  visit_prim<2>(S, prim, L.r, L.T, C, policy);
 }
 __device__ __forceinline__ void step_tri(const DScene& S, Lane& L, Counters& C, unsigned& gmask) {
   double t, u, v;
@@ -1671,7 +1673,8 @@ void rtc_launch_quantize(const double* rgb, unsigned char* out, unsigned long lo
 template <bool COUNT, bool REFILL>
 static void launch_trace_t(int feat, dim3 grid, dim3 block, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb,
                            double* hit_t, int* hit_prim, int* hit_k, DStats* stats, unsigned long long* next_work) {
-  if (feat >= 2) hipLaunchKernelGGL((rtc_trace_kernel<COUNT, REFILL, 2>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
+  if (feat >= 3) hipLaunchKernelGGL((rtc_trace_kernel<COUNT, REFILL, 3>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
+  else if (feat == 2) hipLaunchKernelGGL((rtc_trace_kernel<COUNT, REFILL, 2>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
   else if (feat == 1) hipLaunchKernelGGL((rtc_trace_kernel<COUNT, REFILL, 1>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
   else hipLaunchKernelGGL((rtc_trace_kernel<COUNT, REFILL, 0>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
 }
@@ -1680,7 +1683,7 @@ void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, 
                       DStats* stats, bool count, hipStream_t stream, unsigned refill_blocks, unsigned long long* next_work) {
   if (pm.n == 0) return;
   dim3 block(RTC_BLOCK);
-  const int csg = S.has_csg ? 2 : (S.has_groups ? 1 : 0);  // feature level of the kernel instantiation
+  const int csg = S.has_csg ? 3 : (S.has_groups == 2 ? 2 : (S.has_groups ? 1 : 0));  // feature level of the kernel instantiation
   if (refill_blocks) {  // v3: persistent grid; next_work was set to refill_blocks * RTC_BLOCK by the caller
     dim3 grid(refill_blocks);
     if (count) launch_trace_t<true, true>(csg, grid, block, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);

@@ -447,8 +447,10 @@ struct HostArrays {
     d.has_mesh = 0;
     d.has_csg = 0;
     d.has_groups = 0;
-    for (const DPrim& q : prims) if (q.gcond >= 0) d.has_groups = 1;
     for (const DOp& o : ops) if (o.g >= 0) d.has_groups = 1;
+    // a mesh triangle inherits its OP_MESH gate; only primitives reached one by one need their own
+    for (const DOp& o : ops) if ((o.op == OP_PRIM) && prims[o.a].gcond >= 0) d.has_groups = 2;
+    for (int32_t pi : items) if (prims[pi].gcond >= 0) d.has_groups = 2;
     for (const DOp& o : ops) { if (o.op == OP_MESH) d.has_mesh = 1; if (o.op == OP_CSG) d.has_csg = 1; }
     return d;
   }
