@@ -400,11 +400,14 @@ template <bool MESH, int FEAT>
 __device__ __forceinline__ void bvh_walk(const DScene& S, int root, int frame, const Ray& world, const Ray& o, Trav& T, Counters& C, int* __restrict__ stack, int stride) {
   Frame32 F;
   make_frame(S.bvh_frame + 4 * frame, o, F);
+  const int END = (int)0x80000000;
   int sp = 0;
   int cur = root;
   for (;;) {
     DIAG_LOOP(0);
-    if (cur >= 0) {
+    // "while-while": descend through inner nodes until this lane holds a leaf (or has drained its stack); lanes that
+    // already hold a leaf wait here, so the expensive leaf tests below run with as many lanes as possible.
+    while (cur >= 0) {
       DIAG_LOOP(3);
       const DBvhNode* N = S.bvh + cur;
       C.accel_nodes++;
@@ -418,10 +421,13 @@ __device__ __forceinline__ void bvh_walk(const DScene& S, int root, int frame, c
         stack[sp * stride] = c1;
         sp++;
         cur = c0;
-        continue;
-      } else if (h0) { cur = c0; continue; }
-      else if (h1) { cur = c1; continue; }
-    } else {
+      } else if (h0) cur = c0;
+      else if (h1) cur = c1;
+      else if (sp == 0) cur = END;
+      else { sp--; cur = stack[sp * stride]; }
+    }
+    if (cur == END) return;
+    {
       int first = (~cur) >> 3, cnt = ((~cur) & 7) + 1;
       for (int i = first; i < first + cnt; i++) {
         DIAG_LOOP(1);
@@ -1083,15 +1089,21 @@ __global__ void __launch_bounds__(RTC_BLOCK, (FEAT >= 2 && RTC_WAVES_PER_SIMD < 
               tdx = st.nx * kk - st.ex * n_ratio; tdy = st.ny * kk - st.ey * n_ratio; tdz = st.nz * kk - st.ez * n_ratio;
             }
           }
-          if (do_refr) {
+          // depth-first: the reflection ray (if any) is traced next; only a refraction ray that has to wait is stacked
+          if (do_refr && do_refl) {
             Pending& p = pend[np++];
             p.ox = st.ux; p.oy = st.uy; p.oz = st.uz; p.dx = tdx; p.dy = tdy; p.dz = tdz;
             p.weight = wt; p.fuel = fuel - 1; p.kind = 2;
           }
           if (do_refl) {
-            Pending& p = pend[np++];
-            p.ox = st.px; p.oy = st.py; p.oz = st.pz; p.dx = st.rx; p.dy = st.ry; p.dz = st.rz;
-            p.weight = wr; p.fuel = fuel - 1; p.kind = 1;
+            ray.ox = st.px; ray.oy = st.py; ray.oz = st.pz; ray.dx = st.rx; ray.dy = st.ry; ray.dz = st.rz;
+            weight = wr; fuel = fuel - 1; kind = 1;
+            continue;
+          }
+          if (do_refr) {
+            ray.ox = st.ux; ray.oy = st.uy; ray.oz = st.uz; ray.dx = tdx; ray.dy = tdy; ray.dz = tdz;
+            weight = wt; fuel = fuel - 1; kind = 2;
+            continue;
           }
         }
       }
