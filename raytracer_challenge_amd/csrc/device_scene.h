@@ -70,6 +70,17 @@ struct DPrim {  // 32 bytes
   int32_t pad[2];
 };
 
+// Everything ONE intersection test reads, in one 128-byte line (a divergent wave fetches one line per lane instead of
+// chasing item -> DPrim -> matrix -> limits).  Built by the host from prims / xf_inv / limits; index = primitive index.
+struct DPrimI {
+  int32_t geom;
+  uint32_t flags;
+  int32_t data;    // triangle index (geom >= 5)
+  int32_t gcond;
+  double mn, mx;   // cylinder / cone limits
+  double m[12];    // rows 0..2 of transform_inv
+};
+
 struct DPat {  // pattern node, 192 bytes
   int32_t tag, kind, noise_kind;
   uint32_t octaves;
@@ -87,7 +98,8 @@ struct DScene {
   const DBvhNode* bvh;
   const double* mtri;        // packed leaf-order triangles x {p1, e1, e2}
   const int32_t* mtri_prim;  // -> primitive sequence number
-  const int32_t* item_prim;  // OP_BVH leaf items -> primitive index
+  const DPrimI* pisect;      // per primitive: the intersection record
+  const int32_t* item_prim;  // unused by OP_BVH since its leaf refs carry the primitive index itself (one primitive per leaf)
   const int32_t* quirk_prim; // OP_QUIRK items -> primitive index (cubes, cones)
   const DQuirkGrid* qgrids;
   const uint32_t* qcell;     // per-cell offsets into qitem

@@ -205,7 +205,7 @@ __device__ __forceinline__ int tri_hit(const double* __restrict__ g, const Ray& 
 }
 
 // Geometry::intersect (src/shape.rs:862-885) for one primitive; returns the number of pushes, in push order.
-__device__ __forceinline__ int prim_hits(const DScene& S, const DPrim& P, const Ray& o, double* t, double& u, double& v) {
+__device__ __forceinline__ int prim_hits(const DScene& S, const DPrimI& P, const Ray& o, double* t, double& u, double& v) {
   int n = 0;
   switch (P.geom) {
     case 0: {  // sphere :592-619
@@ -236,7 +236,7 @@ __device__ __forceinline__ int prim_hits(const DScene& S, const DPrim& P, const 
     }
     case 3:
     case 4: {  // cylinder :724-768, cone :770-822
-      double mn = S.limits[2 * P.data], mx = S.limits[2 * P.data + 1];
+      double mn = P.mn, mx = P.mx;
       bool cone = P.geom == 4;
       double a, b, c;
       bool walls;
@@ -294,9 +294,9 @@ __device__ __forceinline__ int prim_hits(const DScene& S, const DPrim& P, const 
 // 3: + CSG.  Keeps the common kernels under the register cliff.
 template <int FEAT>
 __device__ __forceinline__ void visit_prim(const DScene& S, int prim, const Ray& r, Trav& T, Counters& C, int policy) {
-  DPrim P = S.prims[prim];
+  const DPrimI P = S.pisect[prim];
   if (FEAT >= 2 && P.gcond >= 0 && !groups_pass(S, P.gcond, r, T, C)) return;
-  const double* __restrict__ m = S.xf_inv + 12 * P.xform;
+  const double* __restrict__ m = P.m;
   if (P.geom == 1) {
     // Plane (src/shape.rs:621-633) only reads origin.y and direction.y of the object-space ray: evaluate that one row of
     // Ray::transform, in the same order, and skip the other two.
@@ -429,15 +429,16 @@ __device__ __forceinline__ void bvh_walk(const DScene& S, int root, int frame, c
     if (cur == END) return;
     {
       int first = (~cur) >> 3, cnt = ((~cur) & 7) + 1;
-      for (int i = first; i < first + cnt; i++) {
-        DIAG_LOOP(1);
-        if (MESH) {
+      if (MESH) {
+        for (int i = first; i < first + cnt; i++) {
+          DIAG_LOOP(1);
           double t, u, v;
           C.tri_tests++;
           if (tri_hit(S.mtri + 9 * (size_t)i, o, t, u, v)) accept(T, C, S.mtri_prim[i], 1, &t);
-        } else {
-          visit_prim<FEAT>(S, S.item_prim[i], world, T, C, 1);
         }
+      } else {
+        DIAG_LOOP(1);
+        visit_prim<FEAT>(S, first, world, T, C, 1);  // analytic leaf = one primitive, named by the ref itself
       }
       if (T.mode == MODE_SHADOW_ANY && T.shadowed) return;
     }
@@ -471,8 +472,8 @@ __device__ __noinline__ int csg_eval(const DScene& S, int pc, const Ray& r, Trav
       C.group_tests++;
       p = group_box_hit(S.group_box + 6 * op.a, r) ? p + 1 : op.b;
     } else if (op.op == OP_PRIM) {
-      DPrim P = S.prims[op.a];
-      Ray o = to_object(S.xf_inv + 12 * P.xform, r);
+      const DPrimI P = S.pisect[op.a];
+      Ray o = to_object(P.m, r);
       double t[4], u = 0.0, v = 0.0;
       if (P.geom >= 5) C.tri_tests++; else C.analytic_tests++;
       int m = prim_hits(S, P, o, t, u, v);
@@ -1324,9 +1325,10 @@ __device__ __forceinline__ void step_prim(const DScene& S, Lane& L, Counters& C,
   int prim, policy;
   const unsigned i = (unsigned)L.it;
   const bool direct = L.it_kind == IT_DIRECT;
-  if (i >= (direct ? (unsigned)S.n_prims : (unsigned)S.n_items)) { guard_trip(L, S, gmask, G_ITEM); return; }
-  // item_prim, quirk_prim and qitem are one array (absolute indices): only the policy depends on the item kind
-  prim = direct ? L.it : S.item_prim[direct ? 0 : L.it];
+  const bool named = direct || L.it_kind == IT_BVHITEM;  // analytic BVH leaf refs carry the primitive index itself
+  if (i >= (named ? (unsigned)S.n_prims : (unsigned)S.n_items)) { guard_trip(L, S, gmask, G_ITEM); return; }
+  // quirk_prim and qitem are one array (absolute indices): only the policy depends on the item kind
+  prim = named ? L.it : S.item_prim[named ? 0 : L.it];
   policy = direct ? 0 : (L.it_kind == IT_BVHITEM ? 1 : 2);
   L.it++;
   if ((unsigned)prim >= (unsigned)S.n_prims) { L.it--; guard_trip(L, S, gmask, G_PRIM, prim); return; }

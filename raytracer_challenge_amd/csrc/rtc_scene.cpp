@@ -219,7 +219,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     d.quirk_prim = d.item_prim;
     d.qitem = d.item_prim;
   }
-  UP(qgrids); UP(qcell); UP(bvh_frame); UP(csg); UP(prims); UP(xf_inv); UP(xf_matinv); UP(limits);
+  UP(qgrids); UP(qcell); UP(bvh_frame); UP(csg); UP(prims); UP(pisect); UP(xf_inv); UP(xf_matinv); UP(limits);
   UP(tri_geo); UP(tri_nrm); UP(mat); UP(mat_pattern); UP(pats); UP(lights);
 #undef UP
   d.n_ops = (int32_t)H.ops.size();

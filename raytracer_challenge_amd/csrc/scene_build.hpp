@@ -28,6 +28,7 @@ struct ProgramBuilder {
   // step never has to choose between arrays.
   std::vector<int32_t> mtri_prim, items;
   std::vector<int32_t>&item_prim = items, &quirk_prim = items, &qitem = items;
+  std::vector<int32_t> bvh_prims;  // primitives the analytic BVH reaches (their leaf refs carry the index)
   std::vector<DQuirkGrid> qgrids;
   std::vector<uint32_t> qcell;
   std::vector<double> bvh_frame;  // per BVH: centre xyz + inf-norm radius (DOp.c indexes it)
@@ -348,8 +349,13 @@ struct ProgramBuilder {
         std::vector<uint32_t> order;
         uint32_t base = (uint32_t)item_prim.size();
         int32_t fi = 0;
+        size_t first_node = bvh_nodes.size();
         int32_t root = build_tree(items, order, base, false, &fi);
-        for (uint32_t k : order) item_prim.push_back(ids[k]);
+        // analytic leaves hold ONE primitive: the leaf ref carries the primitive index itself (no item indirection)
+        auto direct = [&](int32_t ref) { return ref >= 0 ? ref : ~(int32_t)(((uint32_t)ids[order[((uint32_t)~ref >> 3) - base]] << 3) | 0u); };
+        for (size_t ni = first_node; ni < bvh_nodes.size(); ni++) { bvh_nodes[ni].c0 = direct(bvh_nodes[ni].c0); bvh_nodes[ni].c1 = direct(bvh_nodes[ni].c1); }
+        for (int32_t pi : ids) bvh_prims.push_back(pi);
+        root = direct(root);
         ops.push_back({OP_BVH, root, 0, fi, -1, {0, 0, 0}});
         int32_t q0 = (int32_t)quirk_prim.size();
         for (int32_t pi : ids)
@@ -429,6 +435,8 @@ struct HostArrays {
   std::vector<double> bvh_frame;
   std::vector<DCsg> csg;
   std::vector<DPrim> prims;
+  std::vector<DPrimI> pisect;
+  std::vector<int32_t> bvh_prims;  // host only: primitives the analytic BVH reaches
   std::vector<double> xf_inv, xf_matinv, limits, tri_geo, tri_nrm, mat;
   std::vector<int32_t> mat_pattern;
   std::vector<DPat> pats;
@@ -438,7 +446,7 @@ struct HostArrays {
   DScene view() const {
     DScene d{};
     d.ops = ops.data(); d.group_box = group_box.data(); d.group_parent = group_parent.data(); d.bvh = bvh.data(); d.mtri = mtri.data(); d.mtri_prim = mtri_prim.data();
-    d.item_prim = items.data(); d.quirk_prim = items.data(); d.qgrids = qgrids.data(); d.qcell = qcell.data(); d.bvh_frame = bvh_frame.data(); d.csg = csg.data(); d.qitem = items.data(); d.prims = prims.data(); d.xf_inv = xf_inv.data(); d.xf_matinv = xf_matinv.data(); d.limits = limits.data();
+    d.item_prim = items.data(); d.quirk_prim = items.data(); d.qgrids = qgrids.data(); d.qcell = qcell.data(); d.bvh_frame = bvh_frame.data(); d.csg = csg.data(); d.qitem = items.data(); d.prims = prims.data(); d.pisect = pisect.data(); d.xf_inv = xf_inv.data(); d.xf_matinv = xf_matinv.data(); d.limits = limits.data();
     d.tri_geo = tri_geo.data(); d.tri_nrm = tri_nrm.data(); d.mat = mat.data(); d.mat_pattern = mat_pattern.data(); d.pats = pats.data();
     d.lights = lights.data();
     d.n_ops = (int32_t)ops.size(); d.n_prims = (int32_t)prims.size(); d.n_lights = n_lights; d.all_cast_shadow = all_cast_shadow;
@@ -451,6 +459,7 @@ struct HostArrays {
     // a mesh triangle inherits its OP_MESH gate; only primitives reached one by one need their own
     for (const DOp& o : ops) if ((o.op == OP_PRIM) && prims[o.a].gcond >= 0) d.has_groups = 2;
     for (int32_t pi : items) if (prims[pi].gcond >= 0) d.has_groups = 2;
+    for (int32_t pi : bvh_prims) if (prims[pi].gcond >= 0) d.has_groups = 2;
     for (const DOp& o : ops) { if (o.op == OP_MESH) d.has_mesh = 1; if (o.op == OP_CSG) d.has_csg = 1; }
     return d;
   }
@@ -476,6 +485,16 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
     std::memcpy(&H->xf_matinv[(size_t)i * 16], D.xforms[i].material_inv, 16 * sizeof(double));
   }
   H->limits.assign(D.limits, D.limits + (size_t)D.n_limits * 2);
+  H->pisect.resize(D.n_prims);
+  for (uint32_t i = 0; i < D.n_prims; i++) {
+    const DPrim& P = H->prims[i];
+    DPrimI& q = H->pisect[i];
+    q.geom = P.geom; q.flags = P.flags; q.data = P.data; q.gcond = P.gcond;
+    const bool lim = P.geom == RTC_CYLINDER || P.geom == RTC_CONE;
+    q.mn = lim ? D.limits[2 * (size_t)P.data] : 0.0;
+    q.mx = lim ? D.limits[2 * (size_t)P.data + 1] : 0.0;
+    std::memcpy(q.m, &H->xf_inv[(size_t)P.xform * 12], 12 * sizeof(double));
+  }
   H->tri_geo.assign(D.tri_p1e1e2, D.tri_p1e1e2 + (size_t)D.n_tris * 9);
   H->tri_nrm.assign(D.tri_normals, D.tri_normals + (size_t)D.n_tris * 9);
   H->mat.assign((size_t)D.n_materials * 8, 0.0);
@@ -513,6 +532,7 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
   H->mtri = std::move(pb.mtri);
   H->mtri_prim = std::move(pb.mtri_prim);
   H->items = std::move(pb.items);
+  H->bvh_prims = std::move(pb.bvh_prims);
   H->qgrids = std::move(pb.qgrids);
   H->qcell = std::move(pb.qcell);
   H->bvh_frame = std::move(pb.bvh_frame);
