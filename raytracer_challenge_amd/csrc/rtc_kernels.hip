@@ -25,9 +25,6 @@
 #ifndef RTC_WAVES_PER_SIMD
 #define RTC_WAVES_PER_SIMD 1
 #endif
-#ifndef RTC_V2_WAVES_PER_SIMD
-#define RTC_V2_WAVES_PER_SIMD 2
-#endif
 #ifdef RTC_TRAVERSE_NOINLINE
 #define TRAVERSE_INLINE __noinline__
 #else
@@ -1150,518 +1147,6 @@ __global__ void __launch_bounds__(RTC_BLOCK, (FEAT >= 2 && RTC_WAVES_PER_SIMD < 
     atomicAdd(&stats->tri_tests, (unsigned long long)C.tri_tests);
     atomicAdd(&stats->analytic_tests, (unsigned long long)C.analytic_tests);
   }
-}
-
-// =================================================================================================================
-// v2: persistent waves, ONE traversal loop for every ray kind, memory-resident lane contexts, ballot refill.
-//
-// Each lane owns one pixel at a time and walks its ray tree depth-first, but the wave never runs "a primary-ray
-// loop, then a shadow loop": every lane that has a ray in flight (closest / shadow / container pass alike) takes
-// steps of the same resumable traversal state machine, so lanes in different phases of different pixels share the
-// BVH code.  Everything a lane does not need while traversing (hit state, pattern colour, accumulators, pending
-// child rays) lives in a per-lane context in HBM, SoA by lane so the wave's accesses coalesce.  When enough lanes
-// have finished their traversal the wave leaves the loop, runs their continuations (shade / next light / spawn /
-// next pixel via one wave-aggregated atomic) and re-enters.  The exit condition is reached by every wave: a lane
-// becomes EXIT when the pixel counter is exhausted, and the loop ends when all 64 lanes are EXIT.
-// =================================================================================================================
-#ifndef RTC_WAVE
-#define RTC_WAVE 64
-#endif
-#ifndef RTC_V2_WAIT_LANES
-#define RTC_V2_WAIT_LANES 24  // leave the traversal loop once this many lanes wait for their continuation
-#endif
-
-namespace {
-
-enum { PH_IDLE = 0, PH_TRAV = 1, PH_DONE = 2, PH_EXIT = 3 };
-enum { ST_CLOSEST = 0, ST_CONT = 1, ST_SHADOW = 2 };
-#define CUR_NONE ((int)0x80000000)
-
-// context fields (doubles), index f * nl + lane
-enum { CF_HRAY = 0, CF_TRAY = 6, CF_POINT = 12, CF_NORMAL = 15, CF_COLOR = 18, CF_N1 = 21, CF_N2 = 22, CF_ACC = 23, CF_WEIGHT = 26, CF_T = 27, CF_PEND = 28 };
-// context fields (ints)
-enum { CI_PRIM = 0, CI_PEND = 1 };
-
-struct Lane {  // register-resident state of one lane
-  Ray r;              // ray in the space of the structure being walked (world, or object space inside OP_MESH)
-  Frame32 F;          // f32 slab frame of the BVH being walked
-  Trav T;
-  int pc, cur, sp;    // program counter, BVH cursor (CUR_NONE = at op level, CUR_END = BVH drained), stack depth
-  int it, it_end, it_kind;  // pending leaf / list items [it, it_end) and where their primitive ids come from
-  int in_mesh;        // r is an object-space ray
-  int phase, stage, light, fuel, np, kind;
-  unsigned q;         // output slot of the pixel in flight
-  double acc_r, acc_g, acc_b, weight;
-};
-#define CUR_END ((int)0x80000001)
-enum { IT_DIRECT = 0, IT_BVHITEM = 1, IT_QLIN = 2, IT_QGRID = 3, IT_TRI = 4 };
-// What a traversing lane wants to do next; the wave runs one kind per iteration (the most wanted one).
-enum { K_NONE = 0, K_OP = 1, K_INNER = 2, K_PRIM = 3, K_TRI = 4 };
-
-__device__ __forceinline__ void ctx_store_ray(double* __restrict__ cd, size_t nl, size_t lane, int f, const Ray& r) {
-  cd[(f + 0) * nl + lane] = r.ox; cd[(f + 1) * nl + lane] = r.oy; cd[(f + 2) * nl + lane] = r.oz;
-  cd[(f + 3) * nl + lane] = r.dx; cd[(f + 4) * nl + lane] = r.dy; cd[(f + 5) * nl + lane] = r.dz;
-}
-__device__ __forceinline__ Ray ctx_load_ray(const double* __restrict__ cd, size_t nl, size_t lane, int f) {
-  Ray r;
-  r.ox = cd[(f + 0) * nl + lane]; r.oy = cd[(f + 1) * nl + lane]; r.oz = cd[(f + 2) * nl + lane];
-  r.dx = cd[(f + 3) * nl + lane]; r.dy = cd[(f + 4) * nl + lane]; r.dz = cd[(f + 5) * nl + lane];
-  return r;
-}
-
-// Traversal guards: every index a step is about to use is checked against its array; on a violation the lane's
-// traversal is retired (as if the program had ended) and a bit is raised in DStats.guard -> the host reports
-// RTC_ERR_DEVICE instead of the GPU faulting.
-enum { G_NODE = 0, G_ITEM = 1, G_TRI = 2, G_PRIM = 3, G_OP = 4, G_STACK = 5, G_QUIRK = 6 };
-__device__ DStats* g_guard_stats = nullptr;
-__device__ __forceinline__ void guard_trip(Lane& L, const DScene& S, unsigned& gmask, int code, long long value = 0) {
-  gmask |= 1u << code;
-  DStats* st = g_guard_stats;
-  if (st && atomicAdd(&st->guard_claim, 1ull) == 0ull) {
-    st->guard_info[0] = code; st->guard_info[1] = L.it_kind; st->guard_info[2] = L.it; st->guard_info[3] = L.it_end;
-    st->guard_info[4] = value; st->guard_info[5] = L.cur; st->guard_info[6] = L.pc; st->guard_info[7] = L.T.mode;
-  }
-  L.cur = CUR_NONE; L.pc = S.n_ops; L.it = 0; L.it_end = 0; L.sp = 0; L.in_mesh = 0;
-}
-
-__device__ __forceinline__ int bvh_pop(Lane& L, const int* __restrict__ stack, int stride) {
-  if (L.sp == 0) return CUR_END;
-  L.sp--;
-  return stack[L.sp * stride];
-}
-
-// A leaf reference in the cursor becomes a pending item range; the cursor moves on to the next stack entry.
-__device__ __forceinline__ void unpack_leaf(Lane& L, const int* __restrict__ stack, int stride) {
-  if (L.it >= L.it_end && L.cur < 0 && L.cur != CUR_NONE && L.cur != CUR_END) {
-    int first = (~L.cur) >> 3, cnt = ((~L.cur) & 7) + 1;
-    L.it = first; L.it_end = first + cnt;
-    L.it_kind = L.in_mesh ? IT_TRI : IT_BVHITEM;
-    L.cur = bvh_pop(L, stack, stride);
-  }
-}
-__device__ __forceinline__ int lane_kind(const Lane& L) {
-  if (L.phase != PH_TRAV) return K_NONE;
-  if (L.it < L.it_end) return L.it_kind == IT_TRI ? K_TRI : K_PRIM;
-  if (L.cur >= 0) return K_INNER;
-  if (L.cur == CUR_NONE || L.cur == CUR_END) return K_OP;
-  return K_NONE;  // a leaf ref waiting for unpack_leaf (next iteration)
-}
-
-// K_OP: leave a drained BVH, or dispatch the next op of the program.
-__device__ __forceinline__ void step_op(const DScene& S, Lane& L, Counters& C, const double* __restrict__ cd, size_t nl, size_t lane, unsigned& gmask) {
-  if (L.cur == CUR_END) {
-    L.cur = CUR_NONE;
-    L.pc++;
-    if (L.in_mesh) { L.r = ctx_load_ray(cd, nl, lane, CF_TRAY); L.in_mesh = 0; }
-    return;
-  }
-  if (L.pc >= S.n_ops) { L.phase = PH_DONE; return; }
-  if (L.pc < 0) { guard_trip(L, S, gmask, G_OP); return; }
-  DOp op = S.ops[L.pc];
-  if (op.op == OP_PRIM) {
-    L.it = op.a; L.it_end = op.a + 1; L.it_kind = IT_DIRECT;
-    L.pc++;
-  } else if (op.op == OP_GROUP) {
-    C.group_tests++;
-    L.pc = group_box_hit(S.group_box + 6 * op.a, L.r) ? L.pc + 1 : op.b;
-  } else if (op.op == OP_MESH && op.g >= 0 && !groups_pass(S, op.g, L.r, L.T, C)) {
-    L.pc++;
-  } else if (op.op == OP_MESH || op.op == OP_BVH) {
-    if (op.op == OP_MESH) { L.r = to_object(S.xf_inv + 12 * op.b, L.r); L.in_mesh = 1; }
-    make_frame(S.bvh_frame + 4 * op.c, L.r, L.F);
-    L.cur = op.a;
-    L.sp = 0;
-  } else if (op.op == OP_QUIRK) {
-    L.it = op.a; L.it_end = op.a + op.b; L.it_kind = IT_QLIN;
-    L.pc++;
-  } else {  // OP_QGRID: the cell lookup of quirk_grid_scan, items deferred to K_PRIM steps
-    if ((unsigned)op.a >= (unsigned)S.n_qgrids) { guard_trip(L, S, gmask, G_QUIRK); return; }
-    const DQuirkGrid G = S.qgrids[op.a];
-    const Ray& r = L.r;
-    double ax = fabs(r.dx), ay = fabs(r.dy), az = fabs(r.dz);
-    double len2 = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
-    if (!(len2 >= RTC_QGRID_MIN_LEN * RTC_QGRID_MIN_LEN) || !(len2 < DINF)) {
-      L.it = G.lin_first; L.it_end = G.lin_first + G.lin_count; L.it_kind = IT_QLIN;
-    } else {
-      int face;
-      double u, v;
-      if (ax >= ay && ax >= az) { face = r.dx > 0.0 ? 0 : 1; u = r.dy / ax; v = r.dz / ax; }
-      else if (ay >= az) { face = r.dy > 0.0 ? 2 : 3; u = r.dx / ay; v = r.dz / ay; }
-      else { face = r.dz > 0.0 ? 4 : 5; u = r.dx / az; v = r.dy / az; }
-      int iu = (int)((u + 1.0) * 0.5 * (double)G.n), iv = (int)((v + 1.0) * 0.5 * (double)G.n);
-      iu = iu < 0 ? 0 : (iu >= G.n ? G.n - 1 : iu);
-      iv = iv < 0 ? 0 : (iv >= G.n ? G.n - 1 : iv);
-      int cell = G.cell_off + (face * G.n + iv) * G.n + iu;
-      if ((unsigned)(cell + 1) >= (unsigned)S.n_qcell) { guard_trip(L, S, gmask, G_QUIRK); return; }
-      L.it = (int)S.qcell[cell]; L.it_end = (int)S.qcell[cell + 1]; L.it_kind = IT_QGRID;
-    }
-    L.pc++;
-  }
-}
-
-// K_INNER: one BVH node (both children's slabs).
-__device__ __forceinline__ void step_inner(const DScene& S, Lane& L, Counters& C, int* __restrict__ stack, int stride, unsigned& gmask) {
-  if ((unsigned)L.cur >= (unsigned)S.n_bvh) { guard_trip(L, S, gmask, G_NODE); return; }
-  const DBvhNode* N = S.bvh + L.cur;
-  C.accel_nodes++;
-  float lo, hi, n0, n1;
-  t_interval32(L.T, lo, hi);
-  bool h0 = slab32(N->lo0, N->hi0, L.F, lo, hi, n0);
-  bool h1 = slab32(N->lo1, N->hi1, L.F, lo, hi, n1);
-  int c0 = N->c0, c1 = N->c1;
-  if (h0 && h1) {
-    if (n1 < n0) { int tmp = c0; c0 = c1; c1 = tmp; }
-    if (L.sp >= RTC_BVH_STACK) { guard_trip(L, S, gmask, G_STACK); return; }
-    stack[L.sp * stride] = c1;
-    L.sp++;
-    L.cur = c0;
-  } else if (h0) L.cur = c0;
-  else if (h1) L.cur = c1;
-  else L.cur = bvh_pop(L, stack, stride);
-}
-
-// K_PRIM: one analytic primitive (exact test, own matrix).  K_TRI: one packed mesh triangle in object space.
-__device__ __forceinline__ void step_prim(const DScene& S, Lane& L, Counters& C, unsigned& gmask) {
-  int prim, policy;
-  const unsigned i = (unsigned)L.it;
-  const bool direct = L.it_kind == IT_DIRECT;
-  const bool named = direct || L.it_kind == IT_BVHITEM;  // analytic BVH leaf refs carry the primitive index itself
-  if (i >= (named ? (unsigned)S.n_prims : (unsigned)S.n_items)) { guard_trip(L, S, gmask, G_ITEM); return; }
-  // quirk_prim and qitem are one array (absolute indices): only the policy depends on the item kind
-  prim = named ? L.it : S.item_prim[named ? 0 : L.it];
-  policy = direct ? 0 : (L.it_kind == IT_BVHITEM ? 1 : 2);
-  L.it++;
-  if ((unsigned)prim >= (unsigned)S.n_prims) { L.it--; guard_trip(L, S, gmask, G_PRIM, prim); return; }
-  visit_prim<2>(S, prim, L.r, L.T, C, policy);
-}
-__device__ __forceinline__ void step_tri(const DScene& S, Lane& L, Counters& C, unsigned& gmask) {
-  double t, u, v;
-  if ((unsigned)L.it >= (unsigned)S.n_mtri) { guard_trip(L, S, gmask, G_TRI); return; }
-  int i = L.it++;
-  C.tri_tests++;
-  if (tri_hit(S.mtri + 9 * (size_t)i, L.r, t, u, v)) accept(L.T, C, S.mtri_prim[i], 1, &t);
-}
-
-__device__ __forceinline__ void start_traversal(const DScene& S, Lane& L, double* __restrict__ cd, size_t nl, size_t lane) {
-  L.pc = 0; L.cur = CUR_NONE; L.sp = 0; L.in_mesh = 0; L.it = 0; L.it_end = 0; L.it_kind = IT_DIRECT;
-  L.phase = PH_TRAV;
-  if (S.has_mesh) ctx_store_ray(cd, nl, lane, CF_TRAY, L.r);  // only a mesh walk replaces L.r by an object-space ray
-}
-
-}  // namespace
-
-template <bool COUNT>
-__global__ void __launch_bounds__(RTC_WAVE, RTC_V2_WAVES_PER_SIMD) rtc_persist_kernel(DScene S, DCamera cam, DPixelMap pm, int fuel0, double* __restrict__ rgb,
-                                                                                   double* __restrict__ hit_t, int* __restrict__ hit_prim, int* __restrict__ hit_k,
-                                                                                   DStats* __restrict__ stats, unsigned long long* __restrict__ next_pixel,
-                                                                                   double* __restrict__ cd, int* __restrict__ ci) {
-  __shared__ int lds_stack[RTC_BVH_STACK * RTC_WAVE];
-  const int lid = threadIdx.x;  // one wave per block
-  int* stack = lds_stack + lid;
-  const int stride = RTC_WAVE;
-  const size_t nl = (size_t)gridDim.x * RTC_WAVE;
-  const size_t lane = (size_t)blockIdx.x * RTC_WAVE + lid;
-  const int pslots = fuel0 + 2;
-  Counters C = {0, 0, 0, 0, 0};
-  unsigned n_primary = 0, n_shadow = 0, n_reflect = 0, n_refract = 0, n_container = 0;
-  const double NL = (double)S.n_lights;
-
-  Lane L;
-  L.phase = PH_IDLE; L.stage = ST_CLOSEST; L.light = 0; L.fuel = 0; L.np = 0; L.kind = 0; L.q = 0;
-  L.pc = 0; L.cur = CUR_NONE; L.sp = 0; L.in_mesh = 0; L.it = 0; L.it_end = 0; L.it_kind = IT_DIRECT;
-  L.acc_r = L.acc_g = L.acc_b = 0.0; L.weight = 1.0;
-  L.r.ox = L.r.oy = L.r.oz = L.r.dx = L.r.dy = L.r.dz = 0.0;
-  L.F.olx = L.F.oly = L.F.olz = L.F.ohx = L.F.ohy = L.F.ohz = L.F.ix = L.F.iy = L.F.iz = 0.0f;
-  reset_closest(L.T, MODE_CLOSEST);
-  bool first_hit_pending = false;
-  unsigned gmask = 0;
-  g_guard_stats = stats;  // same value from every lane
-
-  for (;;) {
-    // ---------------------------------------------------------------- (a) refill idle lanes with new pixels
-    unsigned long long idle = __ballot(L.phase == PH_IDLE);
-    if (idle) {
-      int n = __popcll(idle);
-      unsigned long long base = 0;
-      int leader = __ffsll((long long)idle) - 1;
-      if (lid == leader) base = atomicAdd(next_pixel, (unsigned long long)n);
-      base = __shfl(base, leader);
-      if (L.phase == PH_IDLE) {
-        unsigned long long mine = base + (unsigned long long)__popcll(idle & ((1ull << lid) - 1ull));
-        if (mine < pm.n) {
-          L.q = (unsigned)mine;
-          if (pm.mode == 3) {
-            const double* rr = pm.rays + 6 * mine;
-            L.r.ox = rr[0]; L.r.oy = rr[1]; L.r.oz = rr[2]; L.r.dx = rr[3]; L.r.dy = rr[4]; L.r.dz = rr[5];
-          } else {
-            uint64_t i;
-            if (pm.mode == 1) i = pm.indices[mine];
-            else i = ((uint64_t)pm.row_first + (mine / cam.hsize) * pm.row_step) * cam.hsize + (mine % cam.hsize);
-            L.r = camera_ray(cam, i);
-          }
-          L.acc_r = 0.0; L.acc_g = 0.0; L.acc_b = 0.0; L.weight = 1.0;
-          L.fuel = fuel0; L.np = 0; L.kind = 0; L.stage = ST_CLOSEST;
-          first_hit_pending = true;
-          n_primary++;
-          reset_closest(L.T, MODE_CLOSEST);
-          ctx_store_ray(cd, nl, lane, CF_HRAY, L.r);
-          start_traversal(S, L, cd, nl, lane);
-        } else {
-          L.phase = PH_EXIT;
-        }
-      }
-    }
-    if (__ballot(L.phase != PH_EXIT) == 0ull) break;
-
-    // ---------------------------------------------------------------- (b) the shared traversal loop
-    // One homogeneous step kind per iteration, chosen by ballot: the kind most lanes are waiting for.
-    for (;;) {
-      unpack_leaf(L, stack, stride);
-      int kd = lane_kind(L);
-      unsigned long long trav = __ballot(L.phase == PH_TRAV);
-      if (trav == 0ull) break;
-      if (__popcll(__ballot(L.phase == PH_DONE)) >= RTC_V2_WAIT_LANES) break;
-      int c_inner = __popcll(__ballot(kd == K_INNER)), c_prim = __popcll(__ballot(kd == K_PRIM));
-      int c_tri = __popcll(__ballot(kd == K_TRI)), c_op = __popcll(__ballot(kd == K_OP));
-      int pick = K_INNER, best = c_inner;
-      if (c_tri > best) { pick = K_TRI; best = c_tri; }
-      if (c_prim > best) { pick = K_PRIM; best = c_prim; }
-      if (c_op > best) { pick = K_OP; best = c_op; }
-      if (best == 0) continue;  // only leaf refs pending: unpack_leaf turns them into items next iteration
-      if (kd == pick) {
-        if (pick == K_INNER) step_inner(S, L, C, stack, stride, gmask);
-        else if (pick == K_TRI) step_tri(S, L, C, gmask);
-        else if (pick == K_PRIM) step_prim(S, L, C, gmask);
-        else step_op(S, L, C, cd, nl, lane, gmask);
-        if (L.T.mode == MODE_SHADOW_ANY && L.T.shadowed) { L.phase = PH_DONE; L.it = 0; L.it_end = 0; }
-      }
-    }
-
-    // ---------------------------------------------------------------- (c) continuations of finished traversals
-    if (L.phase == PH_DONE) {
-      bool next_ray = false;   // fetch the next pending ray of this pixel (or finish the pixel)
-      bool prep = false;       // build the hit state and start the light loop
-      double n1 = 1.0, n2 = 1.0;
-      if (L.stage == ST_CLOSEST) {
-        bool did_hit = L.T.best_prim != 0x7fffffff;
-        if (first_hit_pending) {
-          first_hit_pending = false;
-          if (hit_t) {
-            hit_t[L.q] = did_hit ? L.T.best_t : 0.0;
-            hit_prim[L.q] = did_hit ? L.T.best_prim : -1;
-            hit_k[L.q] = did_hit ? L.T.best_k : 0;
-          }
-        }
-        if (!did_hit) next_ray = true;
-        else {
-          const DPrim P = S.prims[L.T.best_prim];
-          if (S.mat[8 * P.mat + 5] != 0.0) {  // transparency: n1/n2 are consumed -> container pass on the same ray
-            n_container++;
-            L.T.mode = MODE_CONTAINERS;
-            L.T.tlo = -DINF; L.T.thi = L.T.best_t;
-            L.T.c1_prim = -1; L.T.c2_prim = -1; L.T.c1_t = 0.0; L.T.c2_t = 0.0;
-            L.r = ctx_load_ray(cd, nl, lane, CF_HRAY);
-            L.stage = ST_CONT;
-            start_traversal(S, L, cd, nl, lane);
-          } else prep = true;
-        }
-      } else if (L.stage == ST_CONT) {
-        if (L.T.c1_prim >= 0) n1 = S.mat[8 * S.prims[L.T.c1_prim].mat + 6];
-        if (L.T.c2_prim >= 0) n2 = S.mat[8 * S.prims[L.T.c2_prim].mat + 6];
-        prep = true;
-      }
-
-      if (prep) {  // Intersection::prepare_state + Pattern::color_at, stored for the light loop
-        const DPrim P = S.prims[L.T.best_prim];
-        Ray hr = ctx_load_ray(cd, nl, lane, CF_HRAY);
-        double hu, hv;
-        hit_uv(S, P, hr, hu, hv);
-        State st;
-        prepare_state(S, P, hr, L.T.best_t, hu, hv, st);
-        double cr, cg, cb;
-        {
-          const double* mi = S.xf_matinv + 16 * P.xform;
-          double x = mi[0] * st.px + mi[1] * st.py + mi[2] * st.pz + mi[3] * 1.0;
-          double y = mi[4] * st.px + mi[5] * st.py + mi[6] * st.pz + mi[7] * 1.0;
-          double z = mi[8] * st.px + mi[9] * st.py + mi[10] * st.pz + mi[11] * 1.0;
-          double w = mi[12] * st.px + mi[13] * st.py + mi[14] * st.pz + mi[15] * 1.0;
-          const DPat& root = S.pats[S.mat_pattern[P.mat]];
-          if (root.tag == 1) { cr = root.color[0]; cg = root.color[1]; cb = root.color[2]; }
-          else pattern_color(S, S.mat_pattern[P.mat], x, y, z, w, cr, cg, cb);
-        }
-        // over_point / normal are what the light loop and the spawn step need; under_point and reflect are rebuilt there
-        cd[(CF_POINT + 0) * nl + lane] = hr.ox + hr.dx * L.T.best_t;
-        cd[(CF_POINT + 1) * nl + lane] = hr.oy + hr.dy * L.T.best_t;
-        cd[(CF_POINT + 2) * nl + lane] = hr.oz + hr.dz * L.T.best_t;
-        cd[(CF_NORMAL + 0) * nl + lane] = st.nx; cd[(CF_NORMAL + 1) * nl + lane] = st.ny; cd[(CF_NORMAL + 2) * nl + lane] = st.nz;
-        cd[(CF_COLOR + 0) * nl + lane] = cr; cd[(CF_COLOR + 1) * nl + lane] = cg; cd[(CF_COLOR + 2) * nl + lane] = cb;
-        cd[CF_N1 * nl + lane] = n1; cd[CF_N2 * nl + lane] = n2;
-        cd[CF_T * nl + lane] = L.T.best_t;
-        ci[CI_PRIM * nl + lane] = L.T.best_prim;
-        L.light = 0;
-        L.stage = ST_SHADOW;
-        if (S.n_lights == 0) L.light = -1;  // no lights: nothing to add, straight to the spawn step
-      }
-
-      bool spawn = false;
-      if (L.stage == ST_SHADOW && L.phase == PH_DONE && !next_ray) {
-        // hit state back from the context
-        const int hp = ci[CI_PRIM * nl + lane];
-        const DPrim P = S.prims[hp];
-        const double* M = S.mat + 8 * P.mat;
-        double qx = cd[(CF_POINT + 0) * nl + lane], qy = cd[(CF_POINT + 1) * nl + lane], qz = cd[(CF_POINT + 2) * nl + lane];
-        double nx = cd[(CF_NORMAL + 0) * nl + lane], ny = cd[(CF_NORMAL + 1) * nl + lane], nz = cd[(CF_NORMAL + 2) * nl + lane];
-        double opx = qx + nx * EPS, opy = qy + ny * EPS, opz = qz + nz * EPS;  // over_point
-        if (!prep && L.light >= 0) {
-          // a shadow traversal for light L.light just finished: Shape::lighting (src/shape.rs:429-462)
-          const double* LG = S.lights + 6 * L.light;
-          double vx = LG[3] - opx, vy = LG[4] - opy, vz = LG[5] - opz;
-          double distance = sqrt(vx * vx + vy * vy + vz * vz);
-          double ldx = vx / distance, ldy = vy / distance, ldz = vz / distance;
-          bool shadowed;
-          if (S.all_cast_shadow) shadowed = L.T.shadowed != 0;
-          else shadowed = (L.T.best_prim != 0x7fffffff) && (S.prims[L.T.best_prim].flags & 1u) && (L.T.best_t < distance);
-          double cr = cd[(CF_COLOR + 0) * nl + lane], cg = cd[(CF_COLOR + 1) * nl + lane], cb = cd[(CF_COLOR + 2) * nl + lane];
-          double er = cr * LG[0], eg = cg * LG[1], eb = cb * LG[2];
-          double lr = er * M[0], lg = eg * M[0], lb = eb * M[0];
-          double ldn = ldx * nx + ldy * ny + ldz * nz;
-          double dr = 0.0, dg = 0.0, db = 0.0, pr = 0.0, pg = 0.0, pb = 0.0;
-          if (!shadowed && ldn >= 0.0) {
-            dr = er * M[1] * ldn; dg = eg * M[1] * ldn; db = eb * M[1] * ldn;
-            double mlx = -ldx, mly = -ldy, mlz = -ldz;
-            double d2 = 2.0 * (mlx * nx + mly * ny + mlz * nz);
-            double rfx = mlx - nx * d2, rfy = mly - ny * d2, rfz = mlz - nz * d2;
-            double ex = -cd[(CF_HRAY + 3) * nl + lane], ey = -cd[(CF_HRAY + 4) * nl + lane], ez = -cd[(CF_HRAY + 5) * nl + lane];
-            double rde = rfx * ex + rfy * ey + rfz * ez;
-            if (rde > 0.0) {
-              double f = pow(rde, M[3]);
-              pr = LG[0] * M[2] * f; pg = LG[1] * M[2] * f; pb = LG[2] * M[2] * f;
-            }
-          }
-          L.acc_r += L.weight * ((lr + dr) + pr);
-          L.acc_g += L.weight * ((lg + dg) + pg);
-          L.acc_b += L.weight * ((lb + db) + pb);
-          L.light++;
-        }
-        if (L.light >= 0 && L.light < S.n_lights) {
-          // World::is_shadowed (src/world.rs:26-48) for the next light
-          const double* LG = S.lights + 6 * L.light;
-          double vx = LG[3] - opx, vy = LG[4] - opy, vz = LG[5] - opz;
-          double distance = sqrt(vx * vx + vy * vy + vz * vz);
-          L.r.ox = opx; L.r.oy = opy; L.r.oz = opz;
-          L.r.dx = vx / distance; L.r.dy = vy / distance; L.r.dz = vz / distance;
-          n_shadow++;
-          reset_closest(L.T, S.all_cast_shadow ? MODE_SHADOW_ANY : MODE_SHADOW_CLOSEST);
-          if (S.all_cast_shadow) L.T.thi = distance;
-          start_traversal(S, L, cd, nl, lane);
-        } else spawn = true;
-
-        if (spawn) {  // reflected_color / refracted_color (src/world.rs:84-132) as weighted pending rays
-          double reflective = M[4], transparency = M[5];
-          if (L.fuel > 0 && (reflective != 0.0 || transparency != 0.0)) {
-            double w = L.weight;
-            double dx = cd[(CF_HRAY + 3) * nl + lane], dy = cd[(CF_HRAY + 4) * nl + lane], dz = cd[(CF_HRAY + 5) * nl + lane];
-            double ex = -dx, ey = -dy, ez = -dz;
-            bool do_refl = reflective != 0.0, do_refr = transparency != 0.0;
-            double wr = w * NL * reflective, wt = w * NL * transparency;
-            double m1 = cd[CF_N1 * nl + lane], m2 = cd[CF_N2 * nl + lane];
-            if (reflective > 0.0 && transparency > 0.0) {
-              State st;
-              st.ex = ex; st.ey = ey; st.ez = ez; st.nx = nx; st.ny = ny; st.nz = nz;
-              double R = schlick(st, m1, m2);
-              wr *= R;
-              wt *= (1.0 - R);
-            }
-            if (do_refr) {
-              double n_ratio = m1 / m2;
-              double cos_i = ex * nx + ey * ny + ez * nz;
-              double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
-              if (!(sin2_t > 1.0)) {
-                double cos_t = sqrt(1.0 - sin2_t);
-                double kk = n_ratio * cos_i - cos_t;
-                int s = L.np++;
-                size_t b = (size_t)(CF_PEND + 7 * s);
-                cd[(b + 0) * nl + lane] = qx - nx * EPS; cd[(b + 1) * nl + lane] = qy - ny * EPS; cd[(b + 2) * nl + lane] = qz - nz * EPS;  // under_point
-                cd[(b + 3) * nl + lane] = nx * kk - ex * n_ratio; cd[(b + 4) * nl + lane] = ny * kk - ey * n_ratio; cd[(b + 5) * nl + lane] = nz * kk - ez * n_ratio;
-                cd[(b + 6) * nl + lane] = wt;
-                ci[(CI_PEND + s) * nl + lane] = ((L.fuel - 1) << 2) | 2;
-              }
-            }
-            if (do_refl) {
-              double dn = 2.0 * (dx * nx + dy * ny + dz * nz);
-              int s = L.np++;
-              size_t b = (size_t)(CF_PEND + 7 * s);
-              cd[(b + 0) * nl + lane] = opx; cd[(b + 1) * nl + lane] = opy; cd[(b + 2) * nl + lane] = opz;
-              cd[(b + 3) * nl + lane] = dx - nx * dn; cd[(b + 4) * nl + lane] = dy - ny * dn; cd[(b + 5) * nl + lane] = dz - nz * dn;
-              cd[(b + 6) * nl + lane] = wr;
-              ci[(CI_PEND + s) * nl + lane] = ((L.fuel - 1) << 2) | 1;
-            }
-          }
-          next_ray = true;
-        }
-      }
-
-      if (next_ray) {
-        if (L.np > 0) {
-          int s = --L.np;
-          size_t b = (size_t)(CF_PEND + 7 * s);
-          L.r.ox = cd[(b + 0) * nl + lane]; L.r.oy = cd[(b + 1) * nl + lane]; L.r.oz = cd[(b + 2) * nl + lane];
-          L.r.dx = cd[(b + 3) * nl + lane]; L.r.dy = cd[(b + 4) * nl + lane]; L.r.dz = cd[(b + 5) * nl + lane];
-          L.weight = cd[(b + 6) * nl + lane];
-          int fk = ci[(CI_PEND + s) * nl + lane];
-          L.fuel = fk >> 2; L.kind = fk & 3;
-          if (L.kind == 1) n_reflect++; else n_refract++;
-          L.stage = ST_CLOSEST;
-          reset_closest(L.T, MODE_CLOSEST);
-          ctx_store_ray(cd, nl, lane, CF_HRAY, L.r);
-          start_traversal(S, L, cd, nl, lane);
-        } else {
-          rgb[3 * (size_t)L.q + 0] = L.acc_r;
-          rgb[3 * (size_t)L.q + 1] = L.acc_g;
-          rgb[3 * (size_t)L.q + 2] = L.acc_b;
-          L.phase = PH_IDLE;
-        }
-      }
-    }
-    (void)pslots;
-  }
-
-  if (C.nan_ts) atomicAdd(&stats->nan_ts, (unsigned long long)C.nan_ts);
-  if (gmask) atomicOr(&stats->guard, (unsigned long long)gmask);
-  if (COUNT) {
-    atomicAdd(&stats->rays_primary, (unsigned long long)n_primary);
-    atomicAdd(&stats->rays_shadow, (unsigned long long)n_shadow);
-    atomicAdd(&stats->rays_reflect, (unsigned long long)n_reflect);
-    atomicAdd(&stats->rays_refract, (unsigned long long)n_refract);
-    atomicAdd(&stats->rays_container, (unsigned long long)n_container);
-    atomicAdd(&stats->accel_nodes, (unsigned long long)C.accel_nodes);
-    atomicAdd(&stats->group_tests, (unsigned long long)C.group_tests);
-    atomicAdd(&stats->tri_tests, (unsigned long long)C.tri_tests);
-    atomicAdd(&stats->analytic_tests, (unsigned long long)C.analytic_tests);
-  }
-}
-
-// Context sizes for a launch of `lanes` lanes at fuel `fuel` (pending slots: fuel + 2).
-size_t rtc_v2_ctx_doubles(size_t lanes, int fuel) { return (size_t)(CF_PEND + 7 * (fuel + 2)) * lanes; }
-size_t rtc_v2_ctx_ints(size_t lanes, int fuel) { return (size_t)(CI_PEND + (fuel + 2)) * lanes; }
-int rtc_v2_wave(void) { return RTC_WAVE; }
-
-#ifndef RTC_EMU
-// Resident waves per CU for the persistent kernel (occupancy query on the real code object).
-int rtc_v2_waves_per_cu(void) {
-  int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtc_persist_kernel<false>, RTC_WAVE, 0) != hipSuccess || nb <= 0) nb = 4;
-  return nb;
-}
-#endif
-
-void rtc_launch_persist(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
-                        DStats* stats, bool count, unsigned n_waves, unsigned long long* next_pixel, double* ctx_d, int* ctx_i, hipStream_t stream) {
-  if (pm.n == 0 || n_waves == 0) return;
-  dim3 block(RTC_WAVE);
-  dim3 grid(n_waves);
-  if (count) hipLaunchKernelGGL(rtc_persist_kernel<true>, grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_pixel, ctx_d, ctx_i);
-  else hipLaunchKernelGGL(rtc_persist_kernel<false>, grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_pixel, ctx_d, ctx_i);
 }
 
 // ---- host-callable launcher (C++ linkage, used by rtc_scene.cpp) ------------------------------------------

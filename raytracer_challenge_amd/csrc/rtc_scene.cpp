@@ -21,12 +21,6 @@ void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, 
 int rtc_v3_blocks_per_cu(void);
 void rtc_launch_quantize(const double* rgb, unsigned char* out, unsigned long long n, hipStream_t stream);
 int rtc_v1_block(void);
-void rtc_launch_persist(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
-                        DStats* stats, bool count, unsigned n_waves, unsigned long long* next_pixel, double* ctx_d, int* ctx_i, hipStream_t stream);
-size_t rtc_v2_ctx_doubles(size_t lanes, int fuel);
-size_t rtc_v2_ctx_ints(size_t lanes, int fuel);
-int rtc_v2_wave(void);
-int rtc_v2_waves_per_cu(void);
 
 static thread_local std::string g_rtc_err;
 static int rtc_fail(int code, const std::string& m) {
@@ -56,13 +50,9 @@ struct rtc_scene {
   uint64_t* d_idx = nullptr;
   double* d_rays = nullptr;
   uint64_t cap_px = 0, cap_idx = 0, cap_rays = 0;
-  // persistent kernel (v2): pixel counter + per-lane contexts
-  int kernel_version = 2;
-  unsigned long long* d_next = nullptr;
-  double* d_ctx_d = nullptr;
-  int* d_ctx_i = nullptr;
-  size_t cap_ctx_d = 0, cap_ctx_i = 0;
-  unsigned max_waves = 0, max_blocks_v3 = 0;
+  int kernel_version = 1;
+  unsigned long long* d_next = nullptr;  // work counter of the refill variant (RTC_KERNEL=3)
+  unsigned max_blocks_v3 = 0;
   int bvh_depth = 0;
   uint32_t n_bvh_nodes = 0, n_mesh_tris = 0;
 
@@ -108,9 +98,9 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
   HIP_OK(hipSetDevice(s->device));
   HIP_OK(hipMemsetAsync(s->d_stats, 0, sizeof(DStats), s->stream));
   HIP_OK(hipEventRecord(s->ev0, s->stream));
-  if (s->kernel_version == 1) {
+  if (s->kernel_version != 3) {
     rtc_launch_trace(s->d, cam, pm, fuel, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream, 0, s->d_next);
-  } else if (s->kernel_version == 3) {
+  } else {
     // persistent v1 with per-lane refill: the work counter starts after the ids the grid's lanes take implicitly
     unsigned blocks = s->max_blocks_v3;
     uint64_t need = (pm.n + (uint64_t)rtc_v1_block() - 1) / (uint64_t)rtc_v1_block();
@@ -119,29 +109,6 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
     HIP_OK(hipMemcpyAsync(s->d_next, &start, sizeof(start), hipMemcpyHostToDevice, s->stream));
     HIP_OK(hipEventRecord(s->ev0, s->stream));
     rtc_launch_trace(s->d, cam, pm, fuel, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream, blocks, s->d_next);
-  } else {
-    const unsigned wave = (unsigned)rtc_v2_wave();
-    uint64_t need_waves = (pm.n + wave - 1) / wave;
-    unsigned n_waves = (unsigned)std::min<uint64_t>(need_waves, s->max_waves);
-    size_t nd = rtc_v2_ctx_doubles((size_t)n_waves * wave, fuel), ni = rtc_v2_ctx_ints((size_t)n_waves * wave, fuel);
-    if (nd > s->cap_ctx_d) {
-      HIP_OK(hipStreamSynchronize(s->stream));
-      if (s->d_ctx_d) (void)hipFree(s->d_ctx_d);
-      s->d_ctx_d = nullptr; s->cap_ctx_d = 0;
-      HIP_OK(hipMalloc((void**)&s->d_ctx_d, nd * sizeof(double)));
-      s->cap_ctx_d = nd;
-    }
-    if (ni > s->cap_ctx_i) {
-      HIP_OK(hipStreamSynchronize(s->stream));
-      if (s->d_ctx_i) (void)hipFree(s->d_ctx_i);
-      s->d_ctx_i = nullptr; s->cap_ctx_i = 0;
-      HIP_OK(hipMalloc((void**)&s->d_ctx_i, ni * sizeof(int)));
-      s->cap_ctx_i = ni;
-    }
-    HIP_OK(hipMemsetAsync(s->d_next, 0, sizeof(unsigned long long), s->stream));
-    HIP_OK(hipEventRecord(s->ev0, s->stream));
-    rtc_launch_persist(s->d, cam, pm, fuel, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, n_waves, s->d_next,
-                       s->d_ctx_d, s->d_ctx_i, s->stream);
   }
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(s->ev1, s->stream));
@@ -254,19 +221,15 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
   HIP_OK(hipMemset(s->d_stats, 0, sizeof(DStats)));
   HIP_OK(hipMalloc((void**)&s->d_next, sizeof(unsigned long long)));
   {
-    // RTC_KERNEL selects the kernel for A/B runs (all are HIP paths): 1 (default, fastest measured) = one pixel per lane, 8x8 tiles;
-    // 2 = persistent state machine with voted step kinds; 3 = v1 with per-lane refill at ray granularity.
+    // RTC_KERNEL selects the launch shape for A/B runs (both are the same HIP kernel template): 1 (default) = one pixel per lane,
+    // 8x8 tiles; 3 = persistent grid, lanes refill from a global work counter.  (2 was a persistent state machine with voted
+    // step kinds: 2.6x slower than 1 on every configuration, removed)
     const char* kv = std::getenv("RTC_KERNEL");
-    s->kernel_version = kv ? std::atoi(kv) : 1;
-    if (s->kernel_version < 1 || s->kernel_version > 3) s->kernel_version = 1;
+    s->kernel_version = (kv && std::atoi(kv) == 3) ? 3 : 1;
     // hipDeviceGetAttribute, not hipGetDeviceProperties: the property struct's layout differs between ROCm releases and
     // this library may run on the HIP runtime PyTorch loaded first.
     int n_cu = 0;
     HIP_OK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device));
-    int per_cu = rtc_v2_waves_per_cu();
-    if (const char* w = std::getenv("RTC_V2_WAVES_PER_CU")) per_cu = std::max(1, std::atoi(w));
-    s->max_waves = (unsigned)std::max(1, n_cu * per_cu);
-    if (s->d.has_csg && s->kernel_version == 2) s->kernel_version = 1;  // the step machine of v2 has no CSG step; v1/v3 do
     int per_cu3 = rtc_v3_blocks_per_cu();
     if (const char* w = std::getenv("RTC_V3_BLOCKS_PER_CU")) per_cu3 = std::max(1, std::atoi(w));
     s->max_blocks_v3 = (unsigned)std::max(1, n_cu * per_cu3);
@@ -283,8 +246,6 @@ void rtc_scene_destroy(rtc_scene* s) {
   if (s->d_stats) (void)hipFree(s->d_stats);
   if (s->d_rgb) { (void)hipFree(s->d_rgb); (void)hipFree(s->d_hit_t); (void)hipFree(s->d_hit_prim); (void)hipFree(s->d_hit_k); }
   if (s->d_next) (void)hipFree(s->d_next);
-  if (s->d_ctx_d) (void)hipFree(s->d_ctx_d);
-  if (s->d_ctx_i) (void)hipFree(s->d_ctx_i);
   if (s->d_idx) (void)hipFree(s->d_idx);
   if (s->d_rays) (void)hipFree(s->d_rays);
   for (auto& m : s->marker) if (m) (void)hipEventDestroy(m);

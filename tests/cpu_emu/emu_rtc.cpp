@@ -31,19 +31,13 @@ static int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double*
   DStats st;
   std::memset(&st, 0, sizeof(st));
   const char* kv = std::getenv("RTC_KERNEL");
-  if (!kv || kv[0] == '1') {
+  if (!kv || kv[0] != '3') {
     unsigned long long next = 0;
     rtc_launch_trace(s->d, cam, pm, fuel, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr, 0, &next);
-  } else if (kv[0] == '3') {  // v1 with per-lane refill, a small persistent grid
+  } else {  // v1 with per-lane refill, a small persistent grid
     unsigned blocks = (unsigned)std::min<uint64_t>((pm.n + rtc_v1_block() - 1) / rtc_v1_block(), 3);
     unsigned long long next = (unsigned long long)blocks * rtc_v1_block();
     rtc_launch_trace(s->d, cam, pm, fuel, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr, blocks, &next);
-  } else {  // persistent kernel with one-lane "waves" (RTC_WAVE = 1): same lane-level state machine as on the GPU
-    unsigned n_waves = (unsigned)std::min<uint64_t>(pm.n, 7);
-    std::vector<double> cd(rtc_v2_ctx_doubles((size_t)n_waves * rtc_v2_wave(), fuel));
-    std::vector<int> ci(rtc_v2_ctx_ints((size_t)n_waves * rtc_v2_wave(), fuel));
-    unsigned long long next = 0;
-    rtc_launch_persist(s->d, cam, pm, fuel, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, n_waves, &next, cd.data(), ci.data(), nullptr);
   }
   if (hits) for (uint64_t i = 0; i < pm.n; i++) hits[i] = {t[i], p[i], k[i]};
   if (stats) {

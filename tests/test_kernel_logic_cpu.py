@@ -31,22 +31,22 @@ def test_emulated_kernel_matches_oracle(emu, orc, name):
     assert_parity(emu, orc, world, cam, 5, label=name)
 
 
-@pytest.mark.parametrize("version", ["2", "3"])
+@pytest.mark.parametrize("version", ["3"])
 def test_emulated_other_kernel_versions(emu, orc, version, monkeypatch):
-    """The persistent kernels (v2 voted state machine, v3 per-lane refill) through the same emulator (one-lane waves)."""
+    """The refill launch shape (RTC_KERNEL=3: persistent grid, lanes take work ids from a counter) through the same emulator."""
     monkeypatch.setenv("RTC_KERNEL", version)
     for name in ("synthetic_cones_grouped", "teapot_low", "nested_glass", "cube_lattice", "synthetic_mesh_small"):
         cam, world = cases.SMALL_CASES[name]()
         assert_parity(emu, orc, world, cam, 5, label="kernel v%s %s" % (version, name))
 
 
-def test_simt_emulation_of_voted_kernel(orc, monkeypatch):
-    """v2 with 8-lane waves, one thread per lane, ballots through a barrier: exercises votes, refill and suspended lanes."""
+def test_simt_emulation_of_refill_kernel(orc, monkeypatch):
+    """Refill variant with one thread per lane: lanes share the block's stack array and race on the work counter."""
     import subprocess
     from emu_lib import EMU_DIR
     from raytracer_challenge_amd.backend import Backend
     subprocess.run(["make", "-s", "-C", EMU_DIR, "simt"], check=True)
-    monkeypatch.setenv("RTC_KERNEL", "2")
+    monkeypatch.setenv("RTC_KERNEL", "3")
     simt = Backend(os.path.join(EMU_DIR, "_build", "librtc_emu_simt.so"))
     for name in ("teapot_low", "nested_glass"):
         cam, world = cases.SMALL_CASES[name]()
