@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <limits>
 #include <vector>
 
@@ -192,6 +193,76 @@ inline int32_t build(const std::vector<Item>& items, std::vector<DBvhNode>& node
   }
   if (depth) *depth = B.max_depth + 1;
   return ref;
+}
+
+// Folds the binary tree `n2` (root `root2`, indices local to n2) into 4-wide nodes appended to `out`: a node starts from
+// its two children and, while it has a free slot, replaces the inner child with the largest box by that child's two
+// children.  Boxes are copied, not recomputed (already rounded outward).  Returns the new root (global index in `out`).
+// *depth = levels of 4-wide nodes; *stack_need = worst-case entries on the traversal stack (every visited node may
+// push all its other children: need(node) = children - 1 + max need(child); a leaf needs none).
+inline int32_t collapse4(const std::vector<DBvhNode>& n2, int32_t root2, std::vector<DBvhNode4>& out, int* depth, int* stack_need) {
+  struct Child { float lo[3], hi[3]; int32_t ref; };
+  struct Rec {
+    const std::vector<DBvhNode>& n2;
+    std::vector<DBvhNode4>& out;
+    int max_depth = 0;
+    static bool present(const float* lo, const float* hi) { return lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]; }
+    static double area(const Child& c) {
+      double dx = (double)c.hi[0] - c.lo[0], dy = (double)c.hi[1] - c.lo[1], dz = (double)c.hi[2] - c.lo[2];
+      return 2.0 * (dx * dy + dy * dz + dz * dx);
+    }
+    void children_of(int32_t i2, std::vector<Child>& v) const {
+      const DBvhNode& N = n2[(size_t)i2];
+      if (present(N.lo0, N.hi0)) { Child c; std::memcpy(c.lo, N.lo0, 12); std::memcpy(c.hi, N.hi0, 12); c.ref = N.c0; v.push_back(c); }
+      if (present(N.lo1, N.hi1)) { Child c; std::memcpy(c.lo, N.lo1, 12); std::memcpy(c.hi, N.hi1, 12); c.ref = N.c1; v.push_back(c); }
+    }
+    int32_t fold(int32_t i2, int d, int* need) {
+      max_depth = std::max(max_depth, d);
+      std::vector<Child> ch;
+      children_of(i2, ch);
+      while (ch.size() < 4) {
+        int best = -1;
+        double best_area = -1.0;
+        for (size_t k = 0; k < ch.size(); k++)
+          if (ch[k].ref >= 0) {
+            double a = area(ch[k]);
+            if (!(a <= best_area)) { best_area = a; best = (int)k; }  // NaN / inf areas expand first
+          }
+        if (best < 0) break;
+        std::vector<Child> sub;
+        children_of(ch[(size_t)best].ref, sub);
+        if (ch.size() - 1 + sub.size() > 4) break;
+        ch.erase(ch.begin() + best);
+        ch.insert(ch.end(), sub.begin(), sub.end());
+      }
+      int32_t self = (int32_t)out.size();
+      out.emplace_back();
+      int deepest = 0;
+      int32_t refs[4] = {0, 0, 0, 0};
+      for (size_t k = 0; k < ch.size(); k++) {
+        int sub_need = 0;
+        refs[k] = ch[k].ref >= 0 ? fold(ch[k].ref, d + 1, &sub_need) : ch[k].ref;
+        deepest = std::max(deepest, sub_need);
+      }
+      DBvhNode4& N = out[(size_t)self];
+      const float inf = std::numeric_limits<float>::infinity();
+      for (size_t k = 0; k < 4; k++) {
+        bool have = k < ch.size();
+        N.lox[k] = have ? ch[k].lo[0] : inf; N.loy[k] = have ? ch[k].lo[1] : inf; N.loz[k] = have ? ch[k].lo[2] : inf;
+        N.hix[k] = have ? ch[k].hi[0] : -inf; N.hiy[k] = have ? ch[k].hi[1] : -inf; N.hiz[k] = have ? ch[k].hi[2] : -inf;
+        N.c[k] = have ? refs[k] : 0;
+        N.pad[k] = 0;
+      }
+      *need = (ch.empty() ? 0 : (int)ch.size() - 1) + deepest;
+      return self;
+    }
+  };
+  Rec R{n2, out};
+  int need = 0;
+  int32_t r = R.fold(root2, 1, &need);
+  if (depth) *depth = R.max_depth;
+  if (stack_need) *stack_need = need;
+  return r;
 }
 
 }  // namespace bvh

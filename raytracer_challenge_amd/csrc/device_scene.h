@@ -44,6 +44,16 @@ struct DBvhNode {
 };
 static_assert(sizeof(DBvhNode) == 64, "BVH node must be one 64-byte line");
 
+// 128-byte BVH4 node, what the device walks: the builder's binary tree with every other level folded away
+// (bvh::collapse4), so a ray's chain of dependent node fetches is about half as long.  Boxes as above, one
+// float[4] per plane (SoA over the children).  An absent child has an inverted box and ref 0.
+struct alignas(16) DBvhNode4 {
+  float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+  int32_t c[4];
+  int32_t pad[4];
+};
+static_assert(sizeof(DBvhNode4) == 128, "BVH4 node must be one 128-byte line");
+
 // Direction grid of one OP_QGRID: cube map, n x n cells per face; cell c owns qitem[qcell[cell_off + c] .. qcell[cell_off + c + 1]).
 // Rays shorter than RTC_QGRID_MIN_LEN (or non-finite) scan quirk_prim[lin_first .. +lin_count) instead.
 struct DQuirkGrid {
@@ -95,7 +105,7 @@ struct DScene {
   const DOp* ops;
   const int32_t* group_parent;  // per group box index: enclosing aggregation group or -1 (boxes used by OP_GROUP/OP_CSG have -1)
   const double* group_box;   // n_groups x {lo[3], hi[3]} f64 exactly as the reference computed them
-  const DBvhNode* bvh;
+  const DBvhNode4* bvh;
   const double* mtri;        // packed leaf-order triangles x {p1, e1, e2}
   const int32_t* mtri_prim;  // -> primitive sequence number
   const DPrimI* pisect;      // per primitive: the intersection record
@@ -122,6 +132,7 @@ struct DScene {
   int32_t has_csg;           // 1: the program contains an OP_CSG
   int32_t has_groups;        // 0: no gates; 1: only OP_MESH / OP_CSG ops are gated; 2: individual primitives are gated
   // array lengths, for the traversal guards (a bad index retires the lane and raises DStats.guard instead of faulting)
+  int32_t bvh_stack;  // entries each lane's traversal stack needs for this scene's trees (LDS is sized from it at launch)
   int32_t n_bvh, n_items, n_mtri, n_quirk, n_qitem, n_qcell, n_groups, n_qgrids;
 };
 
@@ -151,6 +162,28 @@ struct DStats {  // device-side counters (atomically accumulated per wave)
 };
 
 #define RTC_MAX_FUEL 16
+
+// Wavefront path (rtc_kernels.hip, wf_* kernels): rays of one bounce level live in a queue; per level one closest-hit kernel,
+// one shading kernel (hit state, pattern colour, child rays into the other queue) and one shadow + lighting kernel run over
+// it, so the traversal kernels carry no shading state (half the registers of the one-kernel path -> twice the resident waves).
+// All arrays are SoA rows of `cap` elements.  A ray's colour contribution is stored per level and summed child -> parent in a
+// fixed order afterwards, so a pixel's value does not depend on what else was rendered with it.
+#define RTC_WF_SHADE_COUNT 32  // counts[RTC_WF_SHADE_COUNT + level] = shade records of the level
+#define RTC_WF_OVERFLOW 63     // counts[RTC_WF_OVERFLOW] != 0: a queue overflowed, the frame must be rendered by the one-kernel path
+struct DWave {
+  double* rq[2];        // ray queues (level parity): 7 rows ox oy oz dx dy dz weight
+  double* h_t;          // per ray of the level: closest hit t
+  int32_t* h_prim;      //   primitive (-1 miss / padding)
+  double* h_n12;        //   2 rows: n1, n2
+  double* sr;           // shade records (compact): 13 rows point(3) eye(3) normal(3) colour(3) weight
+  int32_t* sr_mat;      //   material index
+  int32_t* sr_node;     //   ray index within the level
+  double* contrib;      // (levels) x 3 rows: colour contribution of each ray (own surface, later + children)
+  int32_t* child;       // (levels) x 2 rows: index of the reflected / refracted child ray in the next level (-1 none)
+  uint32_t* counts;     // 64 counters: [level] rays of the level, [32 + level] shade records, [63] overflow flag
+  uint32_t cap;
+  uint32_t pad;
+};
 #ifndef RTC_BVH_STACK
-#define RTC_BVH_STACK 48
+#define RTC_BVH_STACK 64
 #endif

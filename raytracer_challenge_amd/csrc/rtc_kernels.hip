@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "device_scene.h"
 
 #define EPS 0.00001
@@ -29,6 +31,26 @@
 #define TRAVERSE_INLINE __noinline__
 #else
 #define TRAVERSE_INLINE __forceinline__
+#endif
+#if defined(RTC_EMU) && !defined(RTC_EMU_SIMT)
+#define RTC_LANE_ID 0  // sequential emulation: every lane is its own wave
+#else
+#define RTC_LANE_ID ((int)(threadIdx.x & 63u))
+#endif
+// wf_shade reserves queue space once per block and iteration (same-address device atomics serialise: one per wave cost 0.4 ms
+// per level); the emulators run it with one-wave blocks
+#if defined(RTC_EMU) && !defined(RTC_EMU_SIMT)
+#define RTC_WF_SHADE_BLOCK 1
+#elif defined(RTC_EMU)
+#define RTC_WF_SHADE_BLOCK 64
+#else
+#define RTC_WF_SHADE_BLOCK 512
+#endif
+// per-lane BVH stacks live in LDS, sized per scene at launch (DScene.bvh_stack entries per lane)
+#ifdef RTC_EMU
+#define RTC_LDS_STACK(name) static int name[RTC_BVH_STACK * RTC_BLOCK]
+#else
+#define RTC_LDS_STACK(name) extern __shared__ int name[]
 #endif
 #define DINF (__builtin_inf())
 
@@ -63,13 +85,18 @@ struct Counters {
 // diag[2r] += cycles a lane spent in region r (every participating lane measures the wave's wall time of the region),
 // diag[2r+1] += 1 per participation; diag[16+2j] += active lanes, diag[16+2j+1] += 1 per executed iteration of loop j.
 #ifdef RTC_DIAG
-__device__ unsigned long long* g_diag = nullptr;
+// accumulated per block in LDS (one wave per block: no cross-wave contention in the hot loops), flushed once at kernel end
+__shared__ unsigned long long s_diag[32];
 #define DIAG_T0() diag_t0_ = __builtin_amdgcn_s_memtime()
-#define DIAG_REGION(r) do { unsigned long long t1_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_diag[2 * (r)], t1_ - diag_t0_); atomicAdd(&g_diag[2 * (r) + 1], 1ull); diag_t0_ = t1_; } while (0)
-#define DIAG_LOOP(j) do { unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) { atomicAdd(&g_diag[16 + 2 * (j)], (unsigned long long)__popcll(m_)); atomicAdd(&g_diag[16 + 2 * (j) + 1], 1ull); } } while (0)
+#define DIAG_REGION(r) do { unsigned long long t1_ = __builtin_amdgcn_s_memtime(); atomicAdd(&s_diag[2 * (r)], t1_ - diag_t0_); atomicAdd(&s_diag[2 * (r) + 1], 1ull); diag_t0_ = t1_; } while (0)
+#define DIAG_SPAN_BEGIN() unsigned long long span_t0_ = __builtin_amdgcn_s_memtime()
+#define DIAG_SPAN_END(r) do { atomicAdd(&s_diag[2 * (r)], __builtin_amdgcn_s_memtime() - span_t0_); atomicAdd(&s_diag[2 * (r) + 1], 1ull); } while (0)
+#define DIAG_LOOP(j) do { unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) { s_diag[16 + 2 * (j)] += (unsigned long long)__popcll(m_); s_diag[16 + 2 * (j) + 1] += 1ull; } } while (0)
 #else
 #define DIAG_T0() do {} while (0)
 #define DIAG_REGION(r) do {} while (0)
+#define DIAG_SPAN_BEGIN() do {} while (0)
+#define DIAG_SPAN_END(r) do {} while (0)
 #define DIAG_LOOP(j) do {} while (0)
 #endif
 
@@ -393,6 +420,19 @@ __device__ __forceinline__ bool slab32(const float* __restrict__ lo, const float
   return fmaxf(tn, tlo) <= fminf(tf, thi) && lo[0] <= hi[0];
 }
 
+__device__ __forceinline__ float4 ld4(const float* p) { float4 v; __builtin_memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ int4 ld4(const int32_t* p) { int4 v; __builtin_memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ bool slab32c(float lx, float ly, float lz, float hx, float hy, float hz, const Frame32& f, float tlo, float thi, float& tn_out) {
+  float t0 = (lx - f.olx) * f.ix, t1 = (hx - f.ohx) * f.ix;
+  float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+  t0 = (ly - f.oly) * f.iy; t1 = (hy - f.ohy) * f.iy;
+  tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+  t0 = (lz - f.olz) * f.iz; t1 = (hz - f.ohz) * f.iz;
+  tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+  tn_out = tn;
+  return fmaxf(tn, tlo) <= fminf(tf, thi) && lx <= hx;
+}
+
 template <bool MESH, int FEAT>
 __device__ __forceinline__ void bvh_walk(const DScene& S, int root, int frame, const Ray& world, const Ray& o, Trav& T, Counters& C, int* __restrict__ stack, int stride) {
   Frame32 F;
@@ -406,25 +446,41 @@ __device__ __forceinline__ void bvh_walk(const DScene& S, int root, int frame, c
     // already hold a leaf wait here, so the expensive leaf tests below run with as many lanes as possible.
     while (cur >= 0) {
       DIAG_LOOP(3);
-      const DBvhNode* N = S.bvh + cur;
+      const DBvhNode4* N = S.bvh + cur;
       C.accel_nodes++;
-      float lo, hi, n0, n1;
+      float lo, hi;
       t_interval32(T, lo, hi);
-      bool h0 = slab32(N->lo0, N->hi0, F, lo, hi, n0);
-      bool h1 = slab32(N->lo1, N->hi1, F, lo, hi, n1);
-      int c0 = N->c0, c1 = N->c1;
-      if (h0 && h1) {
-        if (n1 < n0) { int tmp = c0; c0 = c1; c1 = tmp; }
-        stack[sp * stride] = c1;
-        sp++;
-        cur = c0;
-      } else if (h0) cur = c0;
-      else if (h1) cur = c1;
-      else if (sp == 0) cur = END;
-      else { sp--; cur = stack[sp * stride]; }
+      // the node's seven 16-byte rows: one line, all loads in flight together
+      const float4 lox = ld4(N->lox), loy = ld4(N->loy), loz = ld4(N->loz), hix = ld4(N->hix), hiy = ld4(N->hiy), hiz = ld4(N->hiz);
+      const int4 cc = ld4(N->c);
+      const float FINF = __builtin_inff();
+      float t0, t1, t2, t3;
+      bool h0 = slab32c(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, F, lo, hi, t0);
+      bool h1 = slab32c(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, F, lo, hi, t1);
+      bool h2 = slab32c(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, F, lo, hi, t2);
+      bool h3 = slab32c(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, F, lo, hi, t3);
+      const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+      if (nh == 0) {
+        if (sp == 0) cur = END;
+        else { sp--; cur = stack[sp * stride]; }
+        continue;
+      }
+      // order the (entry distance, child) pairs: a hit's key is finite (min with FLT_MAX also replaces a NaN), a miss's
+      // is +inf, so after the network the first nh pairs are exactly the hits, nearest first
+      const float FMAXV = 3.4028234663852886e38f;
+      t0 = h0 ? fminf(t0, FMAXV) : FINF; t1 = h1 ? fminf(t1, FMAXV) : FINF; t2 = h2 ? fminf(t2, FMAXV) : FINF; t3 = h3 ? fminf(t3, FMAXV) : FINF;
+      int c0 = cc.x, c1 = cc.y, c2 = cc.z, c3 = cc.w;
+#define RTC_CSWAP(ta, ca, tb, cb) { const bool s_ = tb < ta; const float tt_ = s_ ? tb : ta; const int ct_ = s_ ? cb : ca; tb = s_ ? ta : tb; cb = s_ ? ca : cb; ta = tt_; ca = ct_; }
+      RTC_CSWAP(t0, c0, t1, c1) RTC_CSWAP(t2, c2, t3, c3) RTC_CSWAP(t0, c0, t2, c2) RTC_CSWAP(t1, c1, t3, c3) RTC_CSWAP(t1, c1, t2, c2)
+#undef RTC_CSWAP
+      if (nh > 3) { stack[sp * stride] = c3; sp++; }
+      if (nh > 2) { stack[sp * stride] = c2; sp++; }
+      if (nh > 1) { stack[sp * stride] = c1; sp++; }
+      cur = c0;
     }
     if (cur == END) return;
     {
+      DIAG_SPAN_BEGIN();
       int first = (~cur) >> 3, cnt = ((~cur) & 7) + 1;
       if (MESH) {
         for (int i = first; i < first + cnt; i++) {
@@ -437,6 +493,7 @@ __device__ __forceinline__ void bvh_walk(const DScene& S, int root, int frame, c
         DIAG_LOOP(1);
         visit_prim<FEAT>(S, first, world, T, C, 1);  // analytic leaf = one primitive, named by the ref itself
       }
+      DIAG_SPAN_END(6);
       if (T.mode == MODE_SHADOW_ANY && T.shadowed) return;
     }
     if (sp == 0) return;
@@ -534,7 +591,9 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
       for (int i = op.a; i < op.a + op.b; i++) visit_prim<FEAT>(S, S.quirk_prim[i], r, T, C, 2);
       pc++;
     } else if (op.op == OP_QGRID) {
+      DIAG_SPAN_BEGIN();
       quirk_grid_scan<FEAT>(S, S.qgrids[op.a], r, T, C);
+      DIAG_SPAN_END(4);
       pc++;
     } else if (op.op == OP_GROUP) {
       C.group_tests++;
@@ -934,14 +993,15 @@ template <bool COUNT, bool REFILL, int FEAT>
 __global__ void __launch_bounds__(RTC_BLOCK, (FEAT >= 2 && RTC_WAVES_PER_SIMD < 2) ? 2 : RTC_WAVES_PER_SIMD) rtc_trace_kernel(DScene S, DCamera cam, DPixelMap pm, int fuel0, double* __restrict__ rgb, double* __restrict__ hit_t,
                                                         int* __restrict__ hit_prim, int* __restrict__ hit_k, DStats* __restrict__ stats,
                                                         unsigned long long* __restrict__ next_work) {
-  __shared__ int lds_stack[RTC_BVH_STACK * RTC_BLOCK];
+  RTC_LDS_STACK(lds_stack);
   int* stack = lds_stack + threadIdx.x;
   const int stride = RTC_BLOCK;
   Counters C = {0, 0, 0, 0, 0};
   unsigned n_primary = 0, n_shadow = 0, n_reflect = 0, n_refract = 0, n_container = 0;
   const WorkMap wm = make_workmap(pm, cam);
 #ifdef RTC_DIAG
-  g_diag = stats->diag;
+  if (threadIdx.x < 32) s_diag[threadIdx.x] = 0ull;
+  __syncthreads();
   unsigned long long diag_t0_ = 0;
   const unsigned long long diag_k0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1129,8 +1189,10 @@ __global__ void __launch_bounds__(RTC_BLOCK, (FEAT >= 2 && RTC_WAVES_PER_SIMD < 
   }
 
 #ifdef RTC_DIAG
-  atomicAdd(&g_diag[14], __builtin_amdgcn_s_memtime() - diag_k0);
-  atomicAdd(&g_diag[15], 1ull);
+  atomicAdd(&s_diag[14], __builtin_amdgcn_s_memtime() - diag_k0);
+  atomicAdd(&s_diag[15], 1ull);
+  __syncthreads();
+  if (threadIdx.x < 32 && s_diag[threadIdx.x]) atomicAdd(&stats->diag[threadIdx.x], s_diag[threadIdx.x]);
 #endif
   if (COUNT || true) {
     // nan_ts must always be published (error reporting); the rest only in the counting variant
@@ -1148,6 +1210,408 @@ __global__ void __launch_bounds__(RTC_BLOCK, (FEAT >= 2 && RTC_WAVES_PER_SIMD < 
     atomicAdd(&stats->analytic_tests, (unsigned long long)C.analytic_tests);
   }
 }
+
+// =================================================================================================================
+// Wavefront path (DWave in device_scene.h): the same device functions as rtc_trace_kernel, cut into per-level kernels.
+//   wf_trace   closest hit (+ container pass for transparent hits) of every ray of the level
+//   wf_shade   hit state, pattern colour -> shade record; reflected / refracted rays -> the other queue
+//   wf_shadow  per shade record and light: shadow ray + Phong terms -> the ray's colour contribution
+//   wf_reduce  contribution[level] += contributions of its children in level + 1 (reflected first); level 0 writes rgb
+// Every kernel is a grid-stride loop over a count that lives in device memory, so a frame is enqueued without host syncs.
+// =================================================================================================================
+namespace {
+
+// Wave-aggregated queue push: one atomic per wave.  Every lane of the wave must call it (want = false for idle lanes).
+__device__ __forceinline__ unsigned wave_push(unsigned* counter, bool want) {
+  const unsigned long long m = __ballot(want ? 1 : 0);
+  if (m == 0ull) return 0xffffffffu;
+  const int lane = RTC_LANE_ID;
+  const int leader = __ffsll((long long)m) - 1;
+  unsigned base = 0;
+  if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(m));
+  base = __shfl(base, leader);
+  return want ? base + (unsigned)__popcll(m & ((1ull << lane) - 1ull)) : 0xffffffffu;
+}
+__device__ __forceinline__ unsigned wf_count(const DWave& W, int level, unsigned n0) {
+  if (level == 0) return n0;
+  unsigned c = W.counts[level];
+  return c < W.cap ? c : W.cap;
+}
+__device__ __forceinline__ Ray wf_load_ray(const DWave& W, int level, unsigned i, double& weight) {
+  const double* q = W.rq[level & 1];
+  const size_t cap = W.cap;
+  Ray r;
+  r.ox = q[i]; r.oy = q[cap + i]; r.oz = q[2 * cap + i]; r.dx = q[3 * cap + i]; r.dy = q[4 * cap + i]; r.dz = q[5 * cap + i];
+  weight = q[6 * cap + i];
+  return r;
+}
+
+}  // namespace
+
+template <bool COUNT, int FEAT>
+__global__ void __launch_bounds__(RTC_BLOCK, FEAT <= 1 ? 4 : 2) wf_trace(DScene S, DCamera cam, DPixelMap pm, DWave W, int level, unsigned n0, double* __restrict__ hit_t,
+                                                      int* __restrict__ hit_prim, int* __restrict__ hit_k, DStats* __restrict__ stats) {
+  RTC_LDS_STACK(lds_stack);
+  int* stack = lds_stack + threadIdx.x;
+  const int stride = RTC_BLOCK;
+  Counters C = {0, 0, 0, 0, 0};
+  unsigned n_rays = 0, n_container = 0;
+  const WorkMap wm = make_workmap(pm, cam);
+  const unsigned count = wf_count(W, level, n0);
+  const size_t cap = W.cap;
+  double* cb = W.contrib + (size_t)level * 3 * cap;
+  int32_t* ch = W.child + (size_t)level * 2 * cap;
+  for (unsigned base = blockIdx.x * RTC_BLOCK; base < count; base += gridDim.x * RTC_BLOCK) {
+    const unsigned i = base + threadIdx.x;
+    if (i >= count) continue;
+    cb[i] = 0.0; cb[cap + i] = 0.0; cb[2 * cap + i] = 0.0;
+    ch[i] = -1; ch[cap + i] = -1;
+    Ray ray;
+    uint64_t q = 0;
+    if (level == 0) {
+      if (!work_to_slot(wm, i, q)) { W.h_prim[i] = -1; continue; }
+      ray = slot_ray(pm, cam, q);
+    } else {
+      double w_;
+      ray = wf_load_ray(W, level, i, w_);
+    }
+    n_rays++;
+    Trav T;
+    reset_closest(T, MODE_CLOSEST);
+    traverse<FEAT>(S, ray, T, C, stack, stride);
+    const bool did_hit = T.best_prim != 0x7fffffff;
+    if (level == 0 && hit_t) {
+      hit_t[q] = did_hit ? T.best_t : 0.0;
+      hit_prim[q] = did_hit ? T.best_prim : -1;
+      hit_k[q] = did_hit ? T.best_k : 0;
+    }
+    W.h_prim[i] = did_hit ? T.best_prim : -1;
+    if (!did_hit) continue;
+    W.h_t[i] = T.best_t;
+    // n1 / n2 are only consumed when the surface is transparent (src/world.rs:70-78, :110)
+    double n1 = 1.0, n2 = 1.0;
+    if (S.mat[8 * S.prims[T.best_prim].mat + 5] != 0.0) {
+      n_container++;
+      Trav K = T;  // keeps the hit key (thi = best_t, best_prim, best_klast)
+      K.mode = MODE_CONTAINERS;
+      K.tlo = -DINF; K.thi = T.best_t;
+      K.c1_prim = -1; K.c2_prim = -1; K.c1_t = 0.0; K.c2_t = 0.0;
+      traverse<FEAT>(S, ray, K, C, stack, stride);
+      if (K.c1_prim >= 0) n1 = S.mat[8 * S.prims[K.c1_prim].mat + 6];
+      if (K.c2_prim >= 0) n2 = S.mat[8 * S.prims[K.c2_prim].mat + 6];
+    }
+    W.h_n12[i] = n1; W.h_n12[cap + i] = n2;
+  }
+  if (C.nan_ts) atomicAdd(&stats->nan_ts, (unsigned long long)C.nan_ts);
+  if (COUNT) {
+    if (level == 0) atomicAdd(&stats->rays_primary, (unsigned long long)n_rays);
+    atomicAdd(&stats->rays_container, (unsigned long long)n_container);
+    atomicAdd(&stats->accel_nodes, (unsigned long long)C.accel_nodes);
+    atomicAdd(&stats->group_tests, (unsigned long long)C.group_tests);
+    atomicAdd(&stats->tri_tests, (unsigned long long)C.tri_tests);
+    atomicAdd(&stats->analytic_tests, (unsigned long long)C.analytic_tests);
+  }
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(RTC_WF_SHADE_BLOCK) wf_shade(DScene S, DCamera cam, DPixelMap pm, DWave W, int level, unsigned n0, int fuel0, DStats* __restrict__ stats) {
+  __shared__ unsigned s_rec[16], s_child[16];  // per wave: its count, then its base index in the queue
+  const WorkMap wm = make_workmap(pm, cam);
+  const unsigned count = wf_count(W, level, n0);
+  const size_t cap = W.cap;
+  const double L = (double)S.n_lights;
+  const int fuel = fuel0 - level;
+  unsigned n_reflect = 0, n_refract = 0;
+  int32_t* ch = W.child + (size_t)level * 2 * cap;
+  double* nq = W.rq[(level + 1) & 1];
+  const int lane = RTC_LANE_ID;
+  const int wave = (int)(threadIdx.x / (RTC_WF_SHADE_BLOCK >= 64 ? 64 : 1));
+  const int n_waves = RTC_WF_SHADE_BLOCK >= 64 ? RTC_WF_SHADE_BLOCK / 64 : 1;
+  for (unsigned base = blockIdx.x * RTC_WF_SHADE_BLOCK; base < count; base += gridDim.x * RTC_WF_SHADE_BLOCK) {  // block-uniform bound: barriers inside
+    const unsigned i = base + threadIdx.x;
+    int prim = -1;
+    if (i < count) prim = W.h_prim[i];
+    const bool hit = prim >= 0;
+    State st;
+    double cr = 0.0, cg = 0.0, cbl = 0.0, weight = 1.0, n1 = 1.0, n2 = 1.0;
+    int mat = 0;
+    double reflective = 0.0, transparency = 0.0;
+    if (hit) {
+      Ray ray;
+      if (level == 0) {
+        uint64_t q = 0;
+        (void)work_to_slot(wm, i, q);
+        ray = slot_ray(pm, cam, q);
+      } else {
+        ray = wf_load_ray(W, level, i, weight);
+      }
+      const DPrim P = S.prims[prim];
+      mat = P.mat;
+      const double* M = S.mat + 8 * P.mat;
+      reflective = M[4]; transparency = M[5];
+      double hu, hv;
+      hit_uv(S, P, ray, hu, hv);
+      prepare_state(S, P, ray, W.h_t[i], hu, hv, st);
+      n1 = W.h_n12[i]; n2 = W.h_n12[cap + i];
+      // Pattern::color_at(material_inv * over_point) — identical for every light (src/shape.rs:437)
+      const double* mi = S.xf_matinv + 16 * P.xform;
+      double x = mi[0] * st.px + mi[1] * st.py + mi[2] * st.pz + mi[3] * 1.0;
+      double y = mi[4] * st.px + mi[5] * st.py + mi[6] * st.pz + mi[7] * 1.0;
+      double z = mi[8] * st.px + mi[9] * st.py + mi[10] * st.pz + mi[11] * 1.0;
+      double w = mi[12] * st.px + mi[13] * st.py + mi[14] * st.pz + mi[15] * 1.0;
+      const DPat& root = S.pats[S.mat_pattern[P.mat]];
+      if (root.tag == 1) { cr = root.color[0]; cg = root.color[1]; cbl = root.color[2]; }
+      else pattern_color(S, S.mat_pattern[P.mat], x, y, z, w, cr, cg, cbl);
+    }
+    // reflected_color / refracted_color (src/world.rs:84-132), once per light in the reference -> factor L
+    bool do_refl = false, do_refr = false;
+    double wr = 0.0, wt = 0.0, tdx = 0.0, tdy = 0.0, tdz = 0.0;
+    if (hit && fuel > 0) {
+      do_refl = reflective != 0.0;
+      do_refr = transparency != 0.0;
+      wr = weight * L * reflective; wt = weight * L * transparency;
+      if (reflective > 0.0 && transparency > 0.0) {
+        double R = schlick(st, n1, n2);
+        wr *= R;
+        wt *= (1.0 - R);
+      }
+      if (do_refr) {
+        double n_ratio = n1 / n2;
+        double cos_i = st.ex * st.nx + st.ey * st.ny + st.ez * st.nz;
+        double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
+        if (sin2_t > 1.0) do_refr = false;
+        else {
+          double cos_t = sqrt(1.0 - sin2_t);
+          double kk = n_ratio * cos_i - cos_t;
+          tdx = st.nx * kk - st.ex * n_ratio; tdy = st.ny * kk - st.ey * n_ratio; tdz = st.nz * kk - st.ez * n_ratio;
+        }
+      }
+    }
+    // queue space: shade records and child rays (a wave's reflected rays first, then its refracted ones); one pair of
+    // atomics per block and iteration
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long m_rec = __ballot(hit ? 1 : 0), m_refl = __ballot(do_refl ? 1 : 0), m_refr = __ballot(do_refr ? 1 : 0);
+    if (lane == 0) { s_rec[wave] = (unsigned)__popcll(m_rec); s_child[wave] = (unsigned)(__popcll(m_refl) + __popcll(m_refr)); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned tr = 0, tc = 0;
+      for (int w = 0; w < n_waves; w++) { tr += s_rec[w]; tc += s_child[w]; }
+      unsigned br = tr ? atomicAdd(&W.counts[RTC_WF_SHADE_COUNT + level], tr) : 0u;
+      unsigned bc = tc ? atomicAdd(&W.counts[level + 1], tc) : 0u;
+      if ((unsigned long long)br + tr > W.cap || (unsigned long long)bc + tc > W.cap) W.counts[RTC_WF_OVERFLOW] = 1u;
+      for (int w = 0; w < n_waves; w++) {
+        unsigned r = s_rec[w], c = s_child[w];
+        s_rec[w] = br; s_child[w] = bc;
+        br += r; bc += c;
+      }
+    }
+    __syncthreads();
+    const unsigned s = s_rec[wave] + (unsigned)__popcll(m_rec & lt);
+    const unsigned jr = s_child[wave] + (unsigned)__popcll(m_refl & lt);
+    const unsigned jt = s_child[wave] + (unsigned)__popcll(m_refl) + (unsigned)__popcll(m_refr & lt);
+    __syncthreads();  // the next iteration reuses s_rec / s_child
+    if (hit && s < W.cap) {
+      double* r = W.sr;
+      r[s] = st.px; r[cap + s] = st.py; r[2 * cap + s] = st.pz;
+      r[3 * cap + s] = st.ex; r[4 * cap + s] = st.ey; r[5 * cap + s] = st.ez;
+      r[6 * cap + s] = st.nx; r[7 * cap + s] = st.ny; r[8 * cap + s] = st.nz;
+      r[9 * cap + s] = cr; r[10 * cap + s] = cg; r[11 * cap + s] = cbl;
+      r[12 * cap + s] = weight;
+      W.sr_mat[s] = mat;
+      W.sr_node[s] = (int32_t)i;
+    }
+    if (do_refl && jr < W.cap) {
+      nq[jr] = st.px; nq[cap + jr] = st.py; nq[2 * cap + jr] = st.pz; nq[3 * cap + jr] = st.rx; nq[4 * cap + jr] = st.ry; nq[5 * cap + jr] = st.rz;
+      nq[6 * cap + jr] = wr;
+      ch[i] = (int32_t)jr;
+      n_reflect++;
+    }
+    if (do_refr && jt < W.cap) {
+      nq[jt] = st.ux; nq[cap + jt] = st.uy; nq[2 * cap + jt] = st.uz; nq[3 * cap + jt] = tdx; nq[4 * cap + jt] = tdy; nq[5 * cap + jt] = tdz;
+      nq[6 * cap + jt] = wt;
+      ch[cap + i] = (int32_t)jt;
+      n_refract++;
+    }
+  }
+  if (COUNT) {
+    atomicAdd(&stats->rays_reflect, (unsigned long long)n_reflect);
+    atomicAdd(&stats->rays_refract, (unsigned long long)n_refract);
+  }
+}
+
+template <bool COUNT, int FEAT>
+__global__ void __launch_bounds__(RTC_BLOCK, FEAT <= 1 ? 4 : 2) wf_shadow(DScene S, DWave W, int level, DStats* __restrict__ stats) {
+  RTC_LDS_STACK(lds_stack);
+  int* stack = lds_stack + threadIdx.x;
+  const int stride = RTC_BLOCK;
+  Counters C = {0, 0, 0, 0, 0};
+  unsigned n_shadow = 0;
+  unsigned count = W.counts[RTC_WF_SHADE_COUNT + level];
+  if (count > W.cap) count = W.cap;
+  const size_t cap = W.cap;
+  double* cb = W.contrib + (size_t)level * 3 * cap;
+  const double* r = W.sr;
+  for (unsigned base = blockIdx.x * RTC_BLOCK; base < count; base += gridDim.x * RTC_BLOCK) {
+    const unsigned s = base + threadIdx.x;
+    if (s >= count) continue;
+    const double px = r[s], py = r[cap + s], pz = r[2 * cap + s];
+    // World::shade_hit (src/world.rs:50-82): per light, shadow test + Phong (src/shape.rs:429-462).  First every shadow
+    // ray (only the point is live across the traversals), then the Phong terms with the rest of the record.
+    unsigned long long shadow_mask = 0ull;  // <= 64 lights (checked at scene creation)
+    for (int l = 0; l < S.n_lights; l++) {
+      const double* LG = S.lights + 6 * l;
+      double vx = LG[3] - px, vy = LG[4] - py, vz = LG[5] - pz;
+      double distance = sqrt(vx * vx + vy * vy + vz * vz);
+      Ray sray;
+      sray.ox = px; sray.oy = py; sray.oz = pz;
+      sray.dx = vx / distance; sray.dy = vy / distance; sray.dz = vz / distance;
+      n_shadow++;
+      Trav Sh;
+      reset_closest(Sh, S.all_cast_shadow ? MODE_SHADOW_ANY : MODE_SHADOW_CLOSEST);
+      if (S.all_cast_shadow) Sh.thi = distance;
+      traverse<FEAT>(S, sray, Sh, C, stack, stride);
+      bool shadowed;
+      if (S.all_cast_shadow) shadowed = Sh.shadowed != 0;
+      else shadowed = (Sh.best_prim != 0x7fffffff) && (S.prims[Sh.best_prim].flags & 1u) && (Sh.best_t < distance);
+      if (shadowed) shadow_mask |= 1ull << l;
+    }
+    const double ex = r[3 * cap + s], ey = r[4 * cap + s], ez = r[5 * cap + s];
+    const double nx = r[6 * cap + s], ny = r[7 * cap + s], nz = r[8 * cap + s];
+    const double cr = r[9 * cap + s], cg = r[10 * cap + s], cbl = r[11 * cap + s];
+    const double* M = S.mat + 8 * W.sr_mat[s];
+    const double ambient = M[0], diffuse = M[1], specular = M[2], shininess = M[3];
+    double sr = 0.0, sg = 0.0, sb = 0.0;
+    for (int l = 0; l < S.n_lights; l++) {
+      const double* LG = S.lights + 6 * l;
+      double vx = LG[3] - px, vy = LG[4] - py, vz = LG[5] - pz;
+      double distance = sqrt(vx * vx + vy * vy + vz * vz);
+      const double ldx = vx / distance, ldy = vy / distance, ldz = vz / distance;  // the shadow ray's direction again
+      const bool shadowed = (shadow_mask >> l) & 1ull;
+      double er = cr * LG[0], eg = cg * LG[1], eb = cbl * LG[2];  // effective_color
+      double lr = er * ambient, lg = eg * ambient, lb = eb * ambient;
+      // light vector: (light.origin - point).normalize() — same numbers as the shadow ray direction
+      double ldn = ldx * nx + ldy * ny + ldz * nz;
+      double dr = 0.0, dg = 0.0, db = 0.0, pr = 0.0, pg = 0.0, pb = 0.0;
+      if (!shadowed && ldn >= 0.0) {
+        dr = er * diffuse * ldn; dg = eg * diffuse * ldn; db = eb * diffuse * ldn;
+        // reflect = (-light).reflect(normal)
+        double mlx = -ldx, mly = -ldy, mlz = -ldz;
+        double d2 = 2.0 * (mlx * nx + mly * ny + mlz * nz);
+        double rfx = mlx - nx * d2, rfy = mly - ny * d2, rfz = mlz - nz * d2;
+        double rde = rfx * ex + rfy * ey + rfz * ez;
+        if (rde > 0.0) {
+          double f = pow(rde, shininess);
+          pr = LG[0] * specular * f; pg = LG[1] * specular * f; pb = LG[2] * specular * f;
+        }
+      }
+      sr += (lr + dr) + pr; sg += (lg + dg) + pg; sb += (lb + db) + pb;
+    }
+    const double weight = r[12 * cap + s];
+    const int node = W.sr_node[s];
+    cb[node] = weight * sr; cb[cap + node] = weight * sg; cb[2 * cap + node] = weight * sb;
+  }
+  if (C.nan_ts) atomicAdd(&stats->nan_ts, (unsigned long long)C.nan_ts);
+  if (COUNT) {
+    atomicAdd(&stats->rays_shadow, (unsigned long long)n_shadow);
+    atomicAdd(&stats->accel_nodes, (unsigned long long)C.accel_nodes);
+    atomicAdd(&stats->group_tests, (unsigned long long)C.group_tests);
+    atomicAdd(&stats->tri_tests, (unsigned long long)C.tri_tests);
+    atomicAdd(&stats->analytic_tests, (unsigned long long)C.analytic_tests);
+  }
+}
+
+// contribution[level][i] += contribution[level + 1][reflected child] + contribution[level + 1][refracted child], in that order;
+// at level 0 the sum is the pixel (rgb != nullptr).  last = the deepest level (no children to add).
+__global__ void __launch_bounds__(256) wf_reduce(DCamera cam, DPixelMap pm, DWave W, int level, int last, unsigned n0, double* __restrict__ rgb) {
+  const WorkMap wm = make_workmap(pm, cam);
+  const unsigned count = wf_count(W, level, n0);
+  const size_t cap = W.cap;
+  double* cb = W.contrib + (size_t)level * 3 * cap;
+  const double* nb = W.contrib + (size_t)(level + 1) * 3 * cap;
+  const int32_t* ch = W.child + (size_t)level * 2 * cap;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    double r = cb[i], g = cb[cap + i], b = cb[2 * cap + i];
+    if (!last) {
+      const int a = ch[i], c = ch[cap + i];
+      if (a >= 0) { r += nb[a]; g += nb[cap + a]; b += nb[2 * cap + a]; }
+      if (c >= 0) { r += nb[c]; g += nb[cap + c]; b += nb[2 * cap + c]; }
+    }
+    if (level == 0) {
+      uint64_t q;
+      if (work_to_slot(wm, i, q)) { rgb[3 * q + 0] = r; rgb[3 * q + 1] = g; rgb[3 * q + 2] = b; }
+    } else {
+      cb[i] = r; cb[cap + i] = g; cb[2 * cap + i] = b;
+    }
+  }
+}
+
+static inline unsigned rtc_stack_bytes(const DScene& S) { return (unsigned)S.bvh_stack * RTC_BLOCK * (unsigned)sizeof(int); }
+
+template <bool COUNT>
+static void launch_wf_t(int feat, const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, const DWave& W, unsigned n0, double* rgb, double* hit_t, int* hit_prim,
+                        int* hit_k, DStats* stats, hipStream_t stream, unsigned blocks) {
+  dim3 grid(blocks), block(RTC_BLOCK);
+  for (int level = 0; level <= fuel; level++) {
+    if (feat >= 3) hipLaunchKernelGGL((wf_trace<COUNT, 3>), grid, block, rtc_stack_bytes(S), stream, S, cam, pm, W, level, n0, hit_t, hit_prim, hit_k, stats);
+    else if (feat == 2) hipLaunchKernelGGL((wf_trace<COUNT, 2>), grid, block, rtc_stack_bytes(S), stream, S, cam, pm, W, level, n0, hit_t, hit_prim, hit_k, stats);
+    else if (feat == 1) hipLaunchKernelGGL((wf_trace<COUNT, 1>), grid, block, rtc_stack_bytes(S), stream, S, cam, pm, W, level, n0, hit_t, hit_prim, hit_k, stats);
+    else hipLaunchKernelGGL((wf_trace<COUNT, 0>), grid, block, rtc_stack_bytes(S), stream, S, cam, pm, W, level, n0, hit_t, hit_prim, hit_k, stats);
+    hipLaunchKernelGGL((wf_shade<COUNT>), dim3(std::max(1u, blocks * RTC_BLOCK / (unsigned)RTC_WF_SHADE_BLOCK / 4u)), dim3(RTC_WF_SHADE_BLOCK), 0, stream, S, cam, pm, W, level, n0, fuel, stats);
+    if (feat >= 3) hipLaunchKernelGGL((wf_shadow<COUNT, 3>), grid, block, rtc_stack_bytes(S), stream, S, W, level, stats);
+    else if (feat == 2) hipLaunchKernelGGL((wf_shadow<COUNT, 2>), grid, block, rtc_stack_bytes(S), stream, S, W, level, stats);
+    else if (feat == 1) hipLaunchKernelGGL((wf_shadow<COUNT, 1>), grid, block, rtc_stack_bytes(S), stream, S, W, level, stats);
+    else hipLaunchKernelGGL((wf_shadow<COUNT, 0>), grid, block, rtc_stack_bytes(S), stream, S, W, level, stats);
+  }
+  for (int level = fuel; level >= 0; level--)
+    hipLaunchKernelGGL(wf_reduce, dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, stream, cam, pm, W, level, level == fuel ? 1 : 0, n0, rgb);
+}
+
+// One frame through the wavefront kernels.  The caller zeroed W.counts on the same stream and sized the arrays for
+// W.cap >= the work ids of the launch and fuel + 1 levels; `blocks` = grid size of the per-level kernels.
+void rtc_launch_wavefront(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, const DWave& W, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
+                          DStats* stats, bool count, hipStream_t stream, unsigned blocks) {
+  if (pm.n == 0) return;
+  const int feat = S.has_csg ? 3 : (S.has_groups == 2 ? 2 : (S.has_groups ? 1 : 0));
+  uint64_t n_work = pm.n;
+  if (pm.mode == 2 && cam.hsize >= 8 && pm.n % cam.hsize == 0)
+    n_work = (uint64_t)((cam.hsize + 7) / 8) * ((pm.n / cam.hsize + 7) / 8) * 64;
+  if (count) launch_wf_t<true>(feat, S, cam, pm, fuel, W, (unsigned)n_work, rgb, hit_t, hit_prim, hit_k, stats, stream, blocks);
+  else launch_wf_t<false>(feat, S, cam, pm, fuel, W, (unsigned)n_work, rgb, hit_t, hit_prim, hit_k, stats, stream, blocks);
+}
+// work ids of a launch (tile padding included): the minimum DWave.cap
+uint64_t rtc_wavefront_work(const DCamera& cam, const DPixelMap& pm) {
+  if (pm.mode == 2 && cam.hsize >= 8 && pm.n % cam.hsize == 0) return (uint64_t)((cam.hsize + 7) / 8) * ((pm.n / cam.hsize + 7) / 8) * 64;
+  return pm.n;
+}
+
+#ifdef RTC_PROBE
+// Experiment: closest-hit traversal alone (no shading state), at several register budgets.
+template <int W>
+__global__ void __launch_bounds__(64, W) rtc_probe_closest_kernel(DScene S, const double* __restrict__ rays, unsigned long long n, double* __restrict__ hit_t, int* __restrict__ hit_prim, int* __restrict__ hit_k) {
+  RTC_LDS_STACK(lds_stack);
+  int* stack = lds_stack + threadIdx.x;
+  unsigned long long id = (unsigned long long)blockIdx.x * 64 + threadIdx.x;
+  if (id >= n) return;
+  Ray ray;
+  ray.ox = rays[6 * id]; ray.oy = rays[6 * id + 1]; ray.oz = rays[6 * id + 2]; ray.dx = rays[6 * id + 3]; ray.dy = rays[6 * id + 4]; ray.dz = rays[6 * id + 5];
+  Counters C = {0, 0, 0, 0, 0};
+  Trav T;
+  reset_closest(T, MODE_CLOSEST);
+  traverse<0>(S, ray, T, C, stack, 64);
+  bool did_hit = T.best_prim != 0x7fffffff;
+  hit_t[id] = did_hit ? T.best_t : 0.0;
+  hit_prim[id] = did_hit ? T.best_prim : -1;
+  hit_k[id] = did_hit ? T.best_k : 0;
+}
+void rtc_launch_probe(int w, const DScene& S, const double* rays, unsigned long long n, double* hit_t, int* hit_prim, int* hit_k, hipStream_t stream) {
+  dim3 grid((unsigned)((n + 63) / 64)), block(64);
+  if (w >= 8) hipLaunchKernelGGL(rtc_probe_closest_kernel<8>, grid, block, rtc_stack_bytes(S), stream, S, rays, n, hit_t, hit_prim, hit_k);
+  else if (w >= 6) hipLaunchKernelGGL(rtc_probe_closest_kernel<6>, grid, block, rtc_stack_bytes(S), stream, S, rays, n, hit_t, hit_prim, hit_k);
+  else if (w >= 4) hipLaunchKernelGGL(rtc_probe_closest_kernel<4>, grid, block, rtc_stack_bytes(S), stream, S, rays, n, hit_t, hit_prim, hit_k);
+  else if (w >= 3) hipLaunchKernelGGL(rtc_probe_closest_kernel<3>, grid, block, rtc_stack_bytes(S), stream, S, rays, n, hit_t, hit_prim, hit_k);
+  else hipLaunchKernelGGL(rtc_probe_closest_kernel<2>, grid, block, rtc_stack_bytes(S), stream, S, rays, n, hit_t, hit_prim, hit_k);
+}
+#endif
 
 // ---- host-callable launcher (C++ linkage, used by rtc_scene.cpp) ------------------------------------------
 // Color::clamp (src/color.rs:42-46) over a flat array of channel values.
@@ -1172,10 +1636,10 @@ void rtc_launch_quantize(const double* rgb, unsigned char* out, unsigned long lo
 template <bool COUNT, bool REFILL>
 static void launch_trace_t(int feat, dim3 grid, dim3 block, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb,
                            double* hit_t, int* hit_prim, int* hit_k, DStats* stats, unsigned long long* next_work) {
-  if (feat >= 3) hipLaunchKernelGGL((rtc_trace_kernel<COUNT, REFILL, 3>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
-  else if (feat == 2) hipLaunchKernelGGL((rtc_trace_kernel<COUNT, REFILL, 2>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
-  else if (feat == 1) hipLaunchKernelGGL((rtc_trace_kernel<COUNT, REFILL, 1>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
-  else hipLaunchKernelGGL((rtc_trace_kernel<COUNT, REFILL, 0>), grid, block, 0, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
+  if (feat >= 3) hipLaunchKernelGGL((rtc_trace_kernel<COUNT, REFILL, 3>), grid, block, rtc_stack_bytes(S), stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
+  else if (feat == 2) hipLaunchKernelGGL((rtc_trace_kernel<COUNT, REFILL, 2>), grid, block, rtc_stack_bytes(S), stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
+  else if (feat == 1) hipLaunchKernelGGL((rtc_trace_kernel<COUNT, REFILL, 1>), grid, block, rtc_stack_bytes(S), stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
+  else hipLaunchKernelGGL((rtc_trace_kernel<COUNT, REFILL, 0>), grid, block, rtc_stack_bytes(S), stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats, next_work);
 }
 
 void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,

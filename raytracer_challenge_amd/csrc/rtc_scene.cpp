@@ -21,6 +21,12 @@ void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, 
 int rtc_v3_blocks_per_cu(void);
 void rtc_launch_quantize(const double* rgb, unsigned char* out, unsigned long long n, hipStream_t stream);
 int rtc_v1_block(void);
+void rtc_launch_wavefront(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, const DWave& W, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
+                          DStats* stats, bool count, hipStream_t stream, unsigned blocks);
+uint64_t rtc_wavefront_work(const DCamera& cam, const DPixelMap& pm);
+#ifdef RTC_PROBE
+void rtc_launch_probe(int w, const DScene& S, const double* rays, unsigned long long n, double* hit_t, int* hit_prim, int* hit_k, hipStream_t stream);
+#endif
 
 static thread_local std::string g_rtc_err;
 static int rtc_fail(int code, const std::string& m) {
@@ -53,6 +59,12 @@ struct rtc_scene {
   int kernel_version = 1;
   unsigned long long* d_next = nullptr;  // work counter of the refill variant (RTC_KERNEL=3)
   unsigned max_blocks_v3 = 0;
+  // wavefront path (RTC_KERNEL=4): queues and per-level arrays, grown on demand
+  DWave wave{};
+  void* wave_mem = nullptr;
+  uint64_t wave_cap = 0;
+  int wave_levels = 0;
+  unsigned wave_blocks = 0;
   int bvh_depth = 0;
   uint32_t n_bvh_nodes = 0, n_mesh_tris = 0;
 
@@ -86,6 +98,41 @@ int ensure_px(rtc_scene* s, uint64_t n, bool hits) {
   return RTC_OK;
 }
 
+// Sizes the wavefront arrays for `n_work` level-0 work ids and fuel + 1 levels: every level may hold up to 2 n_work rays
+// (a level that needs more sets the overflow flag and the frame is rendered again by the one-kernel path).
+int ensure_wave(rtc_scene* s, uint64_t n_work, int fuel) {
+  const int levels = fuel + 1;
+  uint64_t cap = std::max<uint64_t>(2 * n_work, 4096);
+  if (cap > 0x7fffff00ull) return rtc_fail(RTC_ERR_UNSUPPORTED, "launch too large for the wavefront path");
+  if (cap <= s->wave_cap && levels <= s->wave_levels) return RTC_OK;
+  cap = std::max(cap, s->wave_cap);
+  const int lv = std::max(levels, s->wave_levels);
+  HIP_OK(hipStreamSynchronize(s->stream));
+  if (s->wave_mem) (void)hipFree(s->wave_mem);
+  s->wave_mem = nullptr; s->wave_cap = 0; s->wave_levels = 0;
+  const uint64_t n_double = cap * (uint64_t)(7 + 7 + 1 + 2 + 13 + 3 * lv);
+  const uint64_t n_int = cap * (uint64_t)(1 + 1 + 1 + 2 * lv) + 64;
+  HIP_OK(hipMalloc(&s->wave_mem, n_double * sizeof(double) + n_int * sizeof(int32_t)));
+  double* d = (double*)s->wave_mem;
+  DWave& W = s->wave;
+  W.rq[0] = d; d += 7 * cap;
+  W.rq[1] = d; d += 7 * cap;
+  W.h_t = d; d += cap;
+  W.h_n12 = d; d += 2 * cap;
+  W.sr = d; d += 13 * cap;
+  W.contrib = d; d += 3 * (uint64_t)lv * cap;
+  int32_t* q = (int32_t*)d;
+  W.h_prim = q; q += cap;
+  W.sr_mat = q; q += cap;
+  W.sr_node = q; q += cap;
+  W.child = q; q += 2 * (uint64_t)lv * cap;
+  W.counts = (uint32_t*)q;
+  W.cap = (uint32_t)cap;
+  s->wave_cap = cap;
+  s->wave_levels = lv;
+  return RTC_OK;
+}
+
 void to_dcam(const rtc_camera& c, DCamera* d) {
   d->hsize = c.hsize; d->vsize = c.vsize;
   d->half_width = c.half_width; d->half_height = c.half_height; d->pixel_size = c.pixel_size;
@@ -98,7 +145,14 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
   HIP_OK(hipSetDevice(s->device));
   HIP_OK(hipMemsetAsync(s->d_stats, 0, sizeof(DStats), s->stream));
   HIP_OK(hipEventRecord(s->ev0, s->stream));
-  if (s->kernel_version != 3) {
+  bool wavefront = s->kernel_version == 4 && pm.n > 0;
+  if (wavefront) {
+    int rc = ensure_wave(s, rtc_wavefront_work(cam, pm), fuel);
+    if (rc != RTC_OK) return rc;
+    HIP_OK(hipMemsetAsync(s->wave.counts, 0, 64 * sizeof(uint32_t), s->stream));
+    HIP_OK(hipEventRecord(s->ev0, s->stream));
+    rtc_launch_wavefront(s->d, cam, pm, fuel, s->wave, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream, s->wave_blocks);
+  } else if (s->kernel_version != 3) {
     rtc_launch_trace(s->d, cam, pm, fuel, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream, 0, s->d_next);
   } else {
     // persistent v1 with per-lane refill: the work counter starts after the ids the grid's lanes take implicitly
@@ -114,6 +168,17 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
   HIP_OK(hipEventRecord(s->ev1, s->stream));
   if (!sync && !stats) return RTC_OK;
   HIP_OK(hipStreamSynchronize(s->stream));
+  if (wavefront) {
+    uint32_t overflow = 0;
+    HIP_OK(hipMemcpy(&overflow, s->wave.counts + RTC_WF_OVERFLOW, sizeof(overflow), hipMemcpyDeviceToHost));
+    if (overflow) {  // a level outgrew its queue: render the launch again with the one-kernel path (always fits)
+      const int kv = s->kernel_version;
+      s->kernel_version = 1;
+      int rc = run(s, cam, pm, fuel, d_rgb, want_hits, stats, count, true);
+      s->kernel_version = kv;
+      return rc;
+    }
+  }
   DStats h;
   HIP_OK(hipMemcpy(&h, s->d_stats, sizeof(h), hipMemcpyDeviceToHost));
   if (stats) {
@@ -195,6 +260,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
   d.all_cast_shadow = H.all_cast_shadow;
   {
     DScene hv = H.view();
+    d.bvh_stack = hv.bvh_stack;
     d.has_mesh = hv.has_mesh;
     d.has_csg = hv.has_csg;
     d.has_groups = hv.has_groups;
@@ -225,7 +291,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     // 8x8 tiles; 3 = persistent grid, lanes refill from a global work counter.  (2 was a persistent state machine with voted
     // step kinds: 2.6x slower than 1 on every configuration, removed)
     const char* kv = std::getenv("RTC_KERNEL");
-    s->kernel_version = (kv && std::atoi(kv) == 3) ? 3 : 1;
+    s->kernel_version = (kv && std::atoi(kv) == 3) ? 3 : ((kv && std::atoi(kv) == 4) ? 4 : 1);
     // hipDeviceGetAttribute, not hipGetDeviceProperties: the property struct's layout differs between ROCm releases and
     // this library may run on the HIP runtime PyTorch loaded first.
     int n_cu = 0;
@@ -233,6 +299,8 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     int per_cu3 = rtc_v3_blocks_per_cu();
     if (const char* w = std::getenv("RTC_V3_BLOCKS_PER_CU")) per_cu3 = std::max(1, std::atoi(w));
     s->max_blocks_v3 = (unsigned)std::max(1, n_cu * per_cu3);
+    s->wave_blocks = (unsigned)std::max(1, n_cu * 64);
+    if (const char* w = std::getenv("RTC_WF_BLOCKS_PER_CU")) s->wave_blocks = (unsigned)std::max(1, n_cu * std::atoi(w));
   }
   *out = s.release();
   return RTC_OK;
@@ -246,6 +314,7 @@ void rtc_scene_destroy(rtc_scene* s) {
   if (s->d_stats) (void)hipFree(s->d_stats);
   if (s->d_rgb) { (void)hipFree(s->d_rgb); (void)hipFree(s->d_hit_t); (void)hipFree(s->d_hit_prim); (void)hipFree(s->d_hit_k); }
   if (s->d_next) (void)hipFree(s->d_next);
+  if (s->wave_mem) (void)hipFree(s->wave_mem);
   if (s->d_idx) (void)hipFree(s->d_idx);
   if (s->d_rays) (void)hipFree(s->d_rays);
   for (auto& m : s->marker) if (m) (void)hipEventDestroy(m);
@@ -354,6 +423,37 @@ int rtc_trace_rays(rtc_scene* s, const double* rays, uint64_t n, int32_t fuel, d
   return RTC_OK;
 }
 
+#ifdef RTC_PROBE
+// Experiment entry: closest hits of n host rays with the slim kernel at register budget w; returns kernel ms (mean of reps).
+extern "C" double rtc_probe_closest(rtc_scene* s, const double* rays, uint64_t n, int w, int reps, rtc_hit* hits) {
+  if (hipSetDevice(s->device) != hipSuccess) return -1.0;
+  if (ensure_px(s, n, true) != RTC_OK) return -1.0;
+  if (n > s->cap_rays) {
+    if (s->d_rays) (void)hipFree(s->d_rays);
+    s->d_rays = nullptr; s->cap_rays = 0;
+    if (hipMalloc((void**)&s->d_rays, n * 6 * sizeof(double)) != hipSuccess) return -1.0;
+    s->cap_rays = n;
+  }
+  (void)hipMemcpyAsync(s->d_rays, rays, n * 6 * sizeof(double), hipMemcpyHostToDevice, s->stream);
+  rtc_launch_probe(w, s->d, s->d_rays, n, s->d_hit_t, s->d_hit_prim, s->d_hit_k, s->stream);  // warm-up
+  (void)hipEventRecord(s->ev0, s->stream);
+  for (int i = 0; i < reps; i++) rtc_launch_probe(w, s->d, s->d_rays, n, s->d_hit_t, s->d_hit_prim, s->d_hit_k, s->stream);
+  (void)hipEventRecord(s->ev1, s->stream);
+  if (hipStreamSynchronize(s->stream) != hipSuccess) return -1.0;
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, s->ev0, s->ev1);
+  if (hits) {
+    std::vector<double> t(n);
+    std::vector<int> p(n), k(n);
+    (void)hipMemcpy(t.data(), s->d_hit_t, n * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(p.data(), s->d_hit_prim, n * sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(k.data(), s->d_hit_k, n * sizeof(int), hipMemcpyDeviceToHost);
+    for (uint64_t i = 0; i < n; i++) hits[i] = {t[i], p[i], k[i]};
+  }
+  return (double)ms / reps;
+}
+#endif
+
 int rtc_quantize_device(rtc_scene* s, const double* rgb_dev, uint64_t n_values, uint8_t* out_dev, int sync) {
   if (!s || (n_values && (!rgb_dev || !out_dev))) return rtc_fail(RTC_ERR_INVALID, "NULL argument");
   HIP_OK(hipSetDevice(s->device));
@@ -415,6 +515,11 @@ int rtc_scene_check(rtc_scene* s) {
   HIP_OK(hipMemcpy(&h, s->d_stats, sizeof(h), hipMemcpyDeviceToHost));
   if (h.guard) return rtc_fail(RTC_ERR_DEVICE, "traversal guard tripped (mask " + std::to_string(h.guard) + ")");
   if (h.nan_ts) return rtc_fail(RTC_ERR_NAN, "a NaN intersection t was produced (the reference panics in Intersection::sort, src/intersection.rs:124)");
+  if (s->kernel_version == 4 && s->wave_mem) {
+    uint32_t overflow = 0;
+    HIP_OK(hipMemcpy(&overflow, s->wave.counts + RTC_WF_OVERFLOW, sizeof(overflow), hipMemcpyDeviceToHost));
+    if (overflow) return rtc_fail(RTC_ERR_UNSUPPORTED, "a wavefront ray queue overflowed in an unsynchronised launch: render this launch synchronously (falls back by itself)");
+  }
   return RTC_OK;
 }
 

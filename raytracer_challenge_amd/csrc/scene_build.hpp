@@ -22,13 +22,14 @@ struct ProgramBuilder {
   const rtc_scene_desc& D;
   std::vector<DOp> ops;
   std::vector<double> group_box;
-  std::vector<DBvhNode> bvh_nodes;
+  std::vector<DBvhNode4> bvh_nodes;
   std::vector<double> mtri;
   // ONE item array serves BVH leaves, linear quirk lists and direction-grid cells (absolute indices): a traversal
   // step never has to choose between arrays.
   std::vector<int32_t> mtri_prim, items;
   std::vector<int32_t>&item_prim = items, &quirk_prim = items, &qitem = items;
   std::vector<int32_t> bvh_prims;  // primitives the analytic BVH reaches (their leaf refs carry the index)
+  int max_stack = 0;  // worst-case traversal stack entries over all trees
   std::vector<DQuirkGrid> qgrids;
   std::vector<uint32_t> qcell;
   std::vector<double> bvh_frame;  // per BVH: centre xyz + inf-norm radius (DOp.c indexes it)
@@ -194,18 +195,25 @@ struct ProgramBuilder {
     return e ? std::atoi(e) : (mesh ? 4 : 1);
   }
   int32_t build_tree(const std::vector<bvh::Item>& items, std::vector<uint32_t>& order, uint32_t base, bool mesh, int32_t* frame_index) {
-    int depth = 0;
+    // binned-SAH binary tree, then every other level folded away (4-wide nodes); if the worst-case traversal stack of
+    // the result does not fit, a median-split tree (balanced) is used instead
+    int depth = 0, depth2 = 0, need = 0;
     size_t n0 = bvh_nodes.size(), o0 = order.size();
     double frame[4];
-    int32_t root = bvh::build(items, bvh_nodes, order, base, &depth, false, leaf_size(mesh), frame);
-    if (depth > RTC_BVH_STACK - 2) {
+    int32_t root = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+      std::vector<DBvhNode> n2;
       bvh_nodes.resize(n0);
       order.resize(o0);
-      root = bvh::build(items, bvh_nodes, order, base, &depth, true, leaf_size(mesh), frame);
+      int32_t root2 = bvh::build(items, n2, order, base, &depth2, attempt == 1, leaf_size(mesh), frame);
+      root = bvh::collapse4(n2, root2, bvh_nodes, &depth, &need);
+      if (need <= RTC_BVH_STACK - 1) break;
     }
+    if (need > RTC_BVH_STACK - 1) { error = "BVH too deep for the traversal stack"; status = RTC_ERR_UNSUPPORTED; }
     *frame_index = (int32_t)(bvh_frame.size() / 4);
     bvh_frame.insert(bvh_frame.end(), frame, frame + 4);
     max_depth = std::max(max_depth, depth);
+    max_stack = std::max(max_stack, need);
     return root;
   }
 
@@ -353,7 +361,8 @@ struct ProgramBuilder {
         int32_t root = build_tree(items, order, base, false, &fi);
         // analytic leaves hold ONE primitive: the leaf ref carries the primitive index itself (no item indirection)
         auto direct = [&](int32_t ref) { return ref >= 0 ? ref : ~(int32_t)(((uint32_t)ids[order[((uint32_t)~ref >> 3) - base]] << 3) | 0u); };
-        for (size_t ni = first_node; ni < bvh_nodes.size(); ni++) { bvh_nodes[ni].c0 = direct(bvh_nodes[ni].c0); bvh_nodes[ni].c1 = direct(bvh_nodes[ni].c1); }
+        for (size_t ni = first_node; ni < bvh_nodes.size(); ni++)
+          for (int32_t& c : bvh_nodes[ni].c) c = direct(c);
         for (int32_t pi : ids) bvh_prims.push_back(pi);
         root = direct(root);
         ops.push_back({OP_BVH, root, 0, fi, -1, {0, 0, 0}});
@@ -427,7 +436,7 @@ struct HostArrays {
   std::vector<DOp> ops;
   std::vector<double> group_box;
   std::vector<int32_t> group_parent;
-  std::vector<DBvhNode> bvh;
+  std::vector<DBvhNode4> bvh;
   std::vector<double> mtri;
   std::vector<int32_t> mtri_prim, items;  // items: BVH leaf items + quirk lists + grid cells, absolute indices
   std::vector<DQuirkGrid> qgrids;
@@ -441,7 +450,7 @@ struct HostArrays {
   std::vector<int32_t> mat_pattern;
   std::vector<DPat> pats;
   std::vector<double> lights;
-  int32_t n_lights = 0, all_cast_shadow = 1, bvh_depth = 0;
+  int32_t n_lights = 0, all_cast_shadow = 1, bvh_depth = 0, bvh_stack = 8;
 
   DScene view() const {
     DScene d{};
@@ -452,6 +461,7 @@ struct HostArrays {
     d.n_ops = (int32_t)ops.size(); d.n_prims = (int32_t)prims.size(); d.n_lights = n_lights; d.all_cast_shadow = all_cast_shadow;
     d.n_bvh = (int32_t)bvh.size(); d.n_items = (int32_t)items.size(); d.n_mtri = (int32_t)mtri_prim.size(); d.n_quirk = (int32_t)items.size();
     d.n_qitem = (int32_t)items.size(); d.n_qcell = (int32_t)qcell.size(); d.n_groups = (int32_t)(group_box.size() / 6); d.n_qgrids = (int32_t)qgrids.size();
+    d.bvh_stack = bvh_stack;
     d.has_mesh = 0;
     d.has_csg = 0;
     d.has_groups = 0;
@@ -471,7 +481,7 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
   if (rc != RTC_OK) return rc;
   if (D.n_lights > 64) { *err = "more than 64 lights"; return RTC_ERR_INVALID; }
   ProgramBuilder pb{D};
-  if (!pb.emit(0, D.n_nodes)) { *err = pb.error; return pb.status; }
+  if (!pb.emit(0, D.n_nodes) || pb.status != RTC_OK) { *err = pb.error; return pb.status != RTC_OK ? pb.status : RTC_ERR_INVALID; }
   H->prims.resize(D.n_prims);
   H->all_cast_shadow = 1;
   for (uint32_t i = 0; i < D.n_prims; i++) {
@@ -538,6 +548,7 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
   H->bvh_frame = std::move(pb.bvh_frame);
   H->csg = std::move(pb.csg);
   H->bvh_depth = pb.max_depth;
+  H->bvh_stack = std::max(8, pb.max_stack + 1);
   return RTC_OK;
 }
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: A/B the kernel versions of the default library on the bench workloads (kernel ms).
-for kv in ${KERNELS:-1 3}; do
+for kv in ${KERNELS:-1 3 4}; do
   RTC_KERNEL=$kv timeout -k 10 200 python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --extra-workloads config3,config3_high ${BENCH_ARGS:-} 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:

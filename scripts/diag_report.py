@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Reads '[rtc-diag] ...' lines (RTC_DIAG build + RTC_DIAG_DUMP=1) and prints region time shares and loop lane utilisation."""
 import sys
-REG = ["closest traversal", "container traversal", "state + pattern", "shadow traversal", "(unused)", "lighting + spawn + pop"]
+REG = ["closest traversal", "container traversal", "state + pattern", "shadow traversal", "  of traversals: quirk grid scans", "lighting + spawn + pop", "  of traversals: BVH leaf tests"]
 LOOPS = ["bvh_walk iteration", "leaf item", "program op", "inner node", "ray iteration", "light iteration"]
 rows = [list(map(int, l.split()[1:])) for l in sys.stdin if l.startswith("[rtc-diag]")]
 if not rows:

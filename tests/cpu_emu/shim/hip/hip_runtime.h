@@ -15,6 +15,8 @@
 #define __launch_bounds__(...)
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 struct uint3_ { unsigned x, y, z; };
+struct float4 { float x, y, z, w; };
+struct int4 { int x, y, z, w; };
 typedef void* hipStream_t;
 using std::fabs; using std::floor;
 // fminf/fmaxf/fabsf come from <cmath> (C functions, NaN-ignoring like the device versions)
@@ -30,6 +32,7 @@ static inline unsigned long long __ballot(int p) { return p ? 1ull : 0ull; }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 template <class T> static inline T __shfl(T v, int) { return v; }
+static inline void __syncthreads() {}  // sequential mode: only meaningful for one-thread blocks
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)          \
   do {                                                                       \
     gridDim.x = (grid).x; blockDim.x = (block).x;                            \
@@ -78,6 +81,7 @@ static inline unsigned long long __ballot(int p) {
 }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+static inline void __syncthreads() { emu_simt::barrier(); }  // blocks are single waves here
 template <class T> static inline T __shfl(T v, int src) {
   using namespace emu_simt;
   static_assert(sizeof(T) <= 8, "shfl payload");

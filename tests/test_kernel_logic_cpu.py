@@ -31,22 +31,25 @@ def test_emulated_kernel_matches_oracle(emu, orc, name):
     assert_parity(emu, orc, world, cam, 5, label=name)
 
 
-@pytest.mark.parametrize("version", ["3"])
+@pytest.mark.parametrize("version", ["3", "4"])
 def test_emulated_other_kernel_versions(emu, orc, version, monkeypatch):
-    """The refill launch shape (RTC_KERNEL=3: persistent grid, lanes take work ids from a counter) through the same emulator."""
+    """RTC_KERNEL=3 (persistent grid, lanes take work ids from a counter) and RTC_KERNEL=4 (wavefront: per-level trace /
+    shade / shadow / reduce kernels over ray queues) through the same emulator."""
     monkeypatch.setenv("RTC_KERNEL", version)
-    for name in ("synthetic_cones_grouped", "teapot_low", "nested_glass", "cube_lattice", "synthetic_mesh_small"):
+    for name in ("synthetic_cones_grouped", "teapot_low", "nested_glass", "cube_lattice", "synthetic_mesh_small", "csg_scene", "patterns_and_noise"):
         cam, world = cases.SMALL_CASES[name]()
         assert_parity(emu, orc, world, cam, 5, label="kernel v%s %s" % (version, name))
 
 
-def test_simt_emulation_of_refill_kernel(orc, monkeypatch):
-    """Refill variant with one thread per lane: lanes share the block's stack array and race on the work counter."""
+@pytest.mark.parametrize("version", ["3", "4"])
+def test_simt_emulation(orc, version, monkeypatch):
+    """One thread per lane: lanes share the block's stack array and race on the work counter (3); wave-aggregated queue
+    pushes with real ballots / shuffles (4)."""
     import subprocess
     from emu_lib import EMU_DIR
     from raytracer_challenge_amd.backend import Backend
     subprocess.run(["make", "-s", "-C", EMU_DIR, "simt"], check=True)
-    monkeypatch.setenv("RTC_KERNEL", "3")
+    monkeypatch.setenv("RTC_KERNEL", version)
     simt = Backend(os.path.join(EMU_DIR, "_build", "librtc_emu_simt.so"))
     for name in ("teapot_low", "nested_glass"):
         cam, world = cases.SMALL_CASES[name]()

@@ -21,7 +21,7 @@ def test_hip_matches_oracle(hip, orc, name):
     assert_parity(hip, orc, world, cam, 5, label=name)
 
 
-@pytest.mark.parametrize("version", ["1", "3"])
+@pytest.mark.parametrize("version", ["1", "3", "4"])
 def test_hip_every_kernel_version(hip, orc, version, monkeypatch):
     """RTC_KERNEL selects the launch shape at scene creation: 1 = pixel per lane (default), 3 = persistent grid with per-lane
     refill.  Both must be bit-exact in hits on analytic, mesh, grouped, glass and CSG scenes."""
