@@ -170,17 +170,20 @@ struct DStats {  // device-side counters (atomically accumulated per wave)
 // fixed order afterwards, so a pixel's value does not depend on what else was rendered with it.
 #define RTC_WF_SHADE_COUNT 32  // counts[RTC_WF_SHADE_COUNT + level] = shade records of the level
 #define RTC_WF_OVERFLOW 63     // counts[RTC_WF_OVERFLOW] != 0: a queue overflowed, the frame must be rendered by the one-kernel path
+#define RTC_WF_CHUNK_NEXT 64   // counts[RTC_WF_CHUNK_NEXT + 8 * launch + xcd]: next chunk of traversal launch `launch` for blocks of that XCD
+#define RTC_WF_COUNTS 256
+#define RTC_WF_CHUNK 128u      // work items per chunk (two wave passes)
 struct DWave {
   double* rq[2];        // ray queues (level parity): 7 rows ox oy oz dx dy dz weight
   double* h_t;          // per ray of the level: closest hit t
   int32_t* h_prim;      //   primitive (-1 miss / padding)
   double* h_n12;        //   2 rows: n1, n2
-  double* sr;           // shade records (compact): 13 rows point(3) eye(3) normal(3) colour(3) weight
-  int32_t* sr_mat;      //   material index
-  int32_t* sr_node;     //   ray index within the level
+  double* sr[2];        // shade records (compact; level parity): 13 rows point(3) eye(3) normal(3) colour(3) weight
+  int32_t* sr_mat[2];   //   material index
+  int32_t* sr_node[2];  //   ray index within the level
   double* contrib;      // (levels) x 3 rows: colour contribution of each ray (own surface, later + children)
   int32_t* child;       // (levels) x 2 rows: index of the reflected / refracted child ray in the next level (-1 none)
-  uint32_t* counts;     // 64 counters: [level] rays of the level, [32 + level] shade records, [63] overflow flag
+  uint32_t* counts;     // RTC_WF_COUNTS counters: [level] rays of the level, [32 + level] shade records, [63] overflow flag, [64..] chunk cursors
   uint32_t cap;
   uint32_t pad;
 };

@@ -52,6 +52,11 @@
 #else
 #define RTC_LDS_STACK(name) extern __shared__ int name[]
 #endif
+#if defined(RTC_EMU) && !defined(RTC_EMU_SIMT)
+#define RTC_WF_LANES 1u
+#else
+#define RTC_WF_LANES 64u
+#endif
 #define DINF (__builtin_inf())
 
 namespace {
@@ -1248,69 +1253,51 @@ __device__ __forceinline__ Ray wf_load_ray(const DWave& W, int level, unsigned i
 
 }  // namespace
 
-template <bool COUNT, int FEAT>
-__global__ void __launch_bounds__(RTC_BLOCK, FEAT <= 1 ? 4 : 2) wf_trace(DScene S, DCamera cam, DPixelMap pm, DWave W, int level, unsigned n0, double* __restrict__ hit_t,
-                                                      int* __restrict__ hit_prim, int* __restrict__ hit_k, DStats* __restrict__ stats) {
-  RTC_LDS_STACK(lds_stack);
-  int* stack = lds_stack + threadIdx.x;
-  const int stride = RTC_BLOCK;
-  Counters C = {0, 0, 0, 0, 0};
-  unsigned n_rays = 0, n_container = 0;
-  const WorkMap wm = make_workmap(pm, cam);
-  const unsigned count = wf_count(W, level, n0);
+// wf_ts work item of the trace role: ray i of `level` (closest hit, container pass for transparent hits).
+template <int FEAT>
+__device__ __forceinline__ void wf_trace_ray(const DScene& S, const DCamera& cam, const DPixelMap& pm, const DWave& W, const WorkMap& wm, int level, unsigned i,
+                                             double* __restrict__ hit_t, int* __restrict__ hit_prim, int* __restrict__ hit_k, int* stack, int stride, Counters& C,
+                                             unsigned& n_rays, unsigned& n_container) {
   const size_t cap = W.cap;
   double* cb = W.contrib + (size_t)level * 3 * cap;
   int32_t* ch = W.child + (size_t)level * 2 * cap;
-  for (unsigned base = blockIdx.x * RTC_BLOCK; base < count; base += gridDim.x * RTC_BLOCK) {
-    const unsigned i = base + threadIdx.x;
-    if (i >= count) continue;
-    cb[i] = 0.0; cb[cap + i] = 0.0; cb[2 * cap + i] = 0.0;
-    ch[i] = -1; ch[cap + i] = -1;
-    Ray ray;
-    uint64_t q = 0;
-    if (level == 0) {
-      if (!work_to_slot(wm, i, q)) { W.h_prim[i] = -1; continue; }
-      ray = slot_ray(pm, cam, q);
-    } else {
-      double w_;
-      ray = wf_load_ray(W, level, i, w_);
-    }
-    n_rays++;
-    Trav T;
-    reset_closest(T, MODE_CLOSEST);
-    traverse<FEAT>(S, ray, T, C, stack, stride);
-    const bool did_hit = T.best_prim != 0x7fffffff;
-    if (level == 0 && hit_t) {
-      hit_t[q] = did_hit ? T.best_t : 0.0;
-      hit_prim[q] = did_hit ? T.best_prim : -1;
-      hit_k[q] = did_hit ? T.best_k : 0;
-    }
-    W.h_prim[i] = did_hit ? T.best_prim : -1;
-    if (!did_hit) continue;
-    W.h_t[i] = T.best_t;
-    // n1 / n2 are only consumed when the surface is transparent (src/world.rs:70-78, :110)
-    double n1 = 1.0, n2 = 1.0;
-    if (S.mat[8 * S.prims[T.best_prim].mat + 5] != 0.0) {
-      n_container++;
-      Trav K = T;  // keeps the hit key (thi = best_t, best_prim, best_klast)
-      K.mode = MODE_CONTAINERS;
-      K.tlo = -DINF; K.thi = T.best_t;
-      K.c1_prim = -1; K.c2_prim = -1; K.c1_t = 0.0; K.c2_t = 0.0;
-      traverse<FEAT>(S, ray, K, C, stack, stride);
-      if (K.c1_prim >= 0) n1 = S.mat[8 * S.prims[K.c1_prim].mat + 6];
-      if (K.c2_prim >= 0) n2 = S.mat[8 * S.prims[K.c2_prim].mat + 6];
-    }
-    W.h_n12[i] = n1; W.h_n12[cap + i] = n2;
+  cb[i] = 0.0; cb[cap + i] = 0.0; cb[2 * cap + i] = 0.0;
+  ch[i] = -1; ch[cap + i] = -1;
+  Ray ray;
+  uint64_t q = 0;
+  if (level == 0) {
+    if (!work_to_slot(wm, i, q)) { W.h_prim[i] = -1; return; }
+    ray = slot_ray(pm, cam, q);
+  } else {
+    double w_;
+    ray = wf_load_ray(W, level, i, w_);
   }
-  if (C.nan_ts) atomicAdd(&stats->nan_ts, (unsigned long long)C.nan_ts);
-  if (COUNT) {
-    if (level == 0) atomicAdd(&stats->rays_primary, (unsigned long long)n_rays);
-    atomicAdd(&stats->rays_container, (unsigned long long)n_container);
-    atomicAdd(&stats->accel_nodes, (unsigned long long)C.accel_nodes);
-    atomicAdd(&stats->group_tests, (unsigned long long)C.group_tests);
-    atomicAdd(&stats->tri_tests, (unsigned long long)C.tri_tests);
-    atomicAdd(&stats->analytic_tests, (unsigned long long)C.analytic_tests);
+  n_rays++;
+  Trav T;
+  reset_closest(T, MODE_CLOSEST);
+  traverse<FEAT>(S, ray, T, C, stack, stride);
+  const bool did_hit = T.best_prim != 0x7fffffff;
+  if (level == 0 && hit_t) {
+    hit_t[q] = did_hit ? T.best_t : 0.0;
+    hit_prim[q] = did_hit ? T.best_prim : -1;
+    hit_k[q] = did_hit ? T.best_k : 0;
   }
+  W.h_prim[i] = did_hit ? T.best_prim : -1;
+  if (!did_hit) return;
+  W.h_t[i] = T.best_t;
+  // n1 / n2 are only consumed when the surface is transparent (src/world.rs:70-78, :110)
+  double n1 = 1.0, n2 = 1.0;
+  if (S.mat[8 * S.prims[T.best_prim].mat + 5] != 0.0) {
+    n_container++;
+    Trav K = T;  // keeps the hit key (thi = best_t, best_prim, best_klast)
+    K.mode = MODE_CONTAINERS;
+    K.tlo = -DINF; K.thi = T.best_t;
+    K.c1_prim = -1; K.c2_prim = -1; K.c1_t = 0.0; K.c2_t = 0.0;
+    traverse<FEAT>(S, ray, K, C, stack, stride);
+    if (K.c1_prim >= 0) n1 = S.mat[8 * S.prims[K.c1_prim].mat + 6];
+    if (K.c2_prim >= 0) n2 = S.mat[8 * S.prims[K.c2_prim].mat + 6];
+  }
+  W.h_n12[i] = n1; W.h_n12[cap + i] = n2;
 }
 
 template <bool COUNT>
@@ -1411,14 +1398,14 @@ __global__ void __launch_bounds__(RTC_WF_SHADE_BLOCK) wf_shade(DScene S, DCamera
     const unsigned jt = s_child[wave] + (unsigned)__popcll(m_refl) + (unsigned)__popcll(m_refr & lt);
     __syncthreads();  // the next iteration reuses s_rec / s_child
     if (hit && s < W.cap) {
-      double* r = W.sr;
+      double* r = W.sr[level & 1];
       r[s] = st.px; r[cap + s] = st.py; r[2 * cap + s] = st.pz;
       r[3 * cap + s] = st.ex; r[4 * cap + s] = st.ey; r[5 * cap + s] = st.ez;
       r[6 * cap + s] = st.nx; r[7 * cap + s] = st.ny; r[8 * cap + s] = st.nz;
       r[9 * cap + s] = cr; r[10 * cap + s] = cg; r[11 * cap + s] = cbl;
       r[12 * cap + s] = weight;
-      W.sr_mat[s] = mat;
-      W.sr_node[s] = (int32_t)i;
+      W.sr_mat[level & 1][s] = mat;
+      W.sr_node[level & 1][s] = (int32_t)i;
     }
     if (do_refl && jr < W.cap) {
       nq[jr] = st.px; nq[cap + jr] = st.py; nq[2 * cap + jr] = st.pz; nq[3 * cap + jr] = st.rx; nq[4 * cap + jr] = st.ry; nq[5 * cap + jr] = st.rz;
@@ -1439,79 +1426,114 @@ __global__ void __launch_bounds__(RTC_WF_SHADE_BLOCK) wf_shade(DScene S, DCamera
   }
 }
 
+// wf_ts work item of the shadow role: shade record s of `level` (per light: shadow ray, then the Phong terms).
+template <int FEAT>
+__device__ __forceinline__ void wf_shadow_rec(const DScene& S, const DWave& W, int level, unsigned s, int* stack, int stride, Counters& C, unsigned& n_shadow) {
+  const size_t cap = W.cap;
+  double* cb = W.contrib + (size_t)level * 3 * cap;
+  const double* r = W.sr[level & 1];
+  const double px = r[s], py = r[cap + s], pz = r[2 * cap + s];
+  // World::shade_hit (src/world.rs:50-82): per light, shadow test + Phong (src/shape.rs:429-462).  First every shadow
+  // ray (only the point is live across the traversals), then the Phong terms with the rest of the record.
+  unsigned long long shadow_mask = 0ull;  // <= 64 lights (checked at scene creation)
+  for (int l = 0; l < S.n_lights; l++) {
+    const double* LG = S.lights + 6 * l;
+    double vx = LG[3] - px, vy = LG[4] - py, vz = LG[5] - pz;
+    double distance = sqrt(vx * vx + vy * vy + vz * vz);
+    Ray sray;
+    sray.ox = px; sray.oy = py; sray.oz = pz;
+    sray.dx = vx / distance; sray.dy = vy / distance; sray.dz = vz / distance;
+    n_shadow++;
+    Trav Sh;
+    reset_closest(Sh, S.all_cast_shadow ? MODE_SHADOW_ANY : MODE_SHADOW_CLOSEST);
+    if (S.all_cast_shadow) Sh.thi = distance;
+    traverse<FEAT>(S, sray, Sh, C, stack, stride);
+    bool shadowed;
+    if (S.all_cast_shadow) shadowed = Sh.shadowed != 0;
+    else shadowed = (Sh.best_prim != 0x7fffffff) && (S.prims[Sh.best_prim].flags & 1u) && (Sh.best_t < distance);
+    if (shadowed) shadow_mask |= 1ull << l;
+  }
+  const double ex = r[3 * cap + s], ey = r[4 * cap + s], ez = r[5 * cap + s];
+  const double nx = r[6 * cap + s], ny = r[7 * cap + s], nz = r[8 * cap + s];
+  const double cr = r[9 * cap + s], cg = r[10 * cap + s], cbl = r[11 * cap + s];
+  const double* M = S.mat + 8 * W.sr_mat[level & 1][s];
+  const double ambient = M[0], diffuse = M[1], specular = M[2], shininess = M[3];
+  double sr = 0.0, sg = 0.0, sb = 0.0;
+  for (int l = 0; l < S.n_lights; l++) {
+    const double* LG = S.lights + 6 * l;
+    double vx = LG[3] - px, vy = LG[4] - py, vz = LG[5] - pz;
+    double distance = sqrt(vx * vx + vy * vy + vz * vz);
+    const double ldx = vx / distance, ldy = vy / distance, ldz = vz / distance;  // the shadow ray's direction again
+    const bool shadowed = (shadow_mask >> l) & 1ull;
+    double er = cr * LG[0], eg = cg * LG[1], eb = cbl * LG[2];  // effective_color
+    double lr = er * ambient, lg = eg * ambient, lb = eb * ambient;
+    // light vector: (light.origin - point).normalize() — same numbers as the shadow ray direction
+    double ldn = ldx * nx + ldy * ny + ldz * nz;
+    double dr = 0.0, dg = 0.0, db = 0.0, pr = 0.0, pg = 0.0, pb = 0.0;
+    if (!shadowed && ldn >= 0.0) {
+      dr = er * diffuse * ldn; dg = eg * diffuse * ldn; db = eb * diffuse * ldn;
+      // reflect = (-light).reflect(normal)
+      double mlx = -ldx, mly = -ldy, mlz = -ldz;
+      double d2 = 2.0 * (mlx * nx + mly * ny + mlz * nz);
+      double rfx = mlx - nx * d2, rfy = mly - ny * d2, rfz = mlz - nz * d2;
+      double rde = rfx * ex + rfy * ey + rfz * ez;
+      if (rde > 0.0) {
+        double f = pow(rde, shininess);
+        pr = LG[0] * specular * f; pg = LG[1] * specular * f; pb = LG[2] * specular * f;
+      }
+    }
+    sr += (lr + dr) + pr; sg += (lg + dg) + pg; sb += (lb + db) + pb;
+  }
+  const double weight = r[12 * cap + s];
+  const int node = W.sr_node[level & 1][s];
+  cb[node] = weight * sr; cb[cap + node] = weight * sg; cb[2 * cap + node] = weight * sb;
+}
+
+// Traversal kernel of the wavefront path: the closest-hit pass of level `tl` and the shadow + lighting pass of level `sl`
+// (either may be -1) as ONE launch, so the two independent passes fill the chip together.  Work is handed out in chunks of
+// RTC_WF_CHUNK items from per-XCD counters (block b belongs to XCD b % 8 and takes chunks b % 8, b % 8 + 8, ...): trace
+// chunks first (the next shading kernel waits for them), then shadow chunks; a wave that finishes early simply takes more.
 template <bool COUNT, int FEAT>
-__global__ void __launch_bounds__(RTC_BLOCK, FEAT <= 1 ? 4 : 2) wf_shadow(DScene S, DWave W, int level, DStats* __restrict__ stats) {
+__global__ void __launch_bounds__(RTC_BLOCK, FEAT <= 1 ? 4 : 2) wf_ts(DScene S, DCamera cam, DPixelMap pm, DWave W, int tl, int sl, unsigned n0, int slot, double* __restrict__ hit_t,
+                                                                     int* __restrict__ hit_prim, int* __restrict__ hit_k, DStats* __restrict__ stats) {
   RTC_LDS_STACK(lds_stack);
   int* stack = lds_stack + threadIdx.x;
   const int stride = RTC_BLOCK;
   Counters C = {0, 0, 0, 0, 0};
-  unsigned n_shadow = 0;
-  unsigned count = W.counts[RTC_WF_SHADE_COUNT + level];
-  if (count > W.cap) count = W.cap;
-  const size_t cap = W.cap;
-  double* cb = W.contrib + (size_t)level * 3 * cap;
-  const double* r = W.sr;
-  for (unsigned base = blockIdx.x * RTC_BLOCK; base < count; base += gridDim.x * RTC_BLOCK) {
-    const unsigned s = base + threadIdx.x;
-    if (s >= count) continue;
-    const double px = r[s], py = r[cap + s], pz = r[2 * cap + s];
-    // World::shade_hit (src/world.rs:50-82): per light, shadow test + Phong (src/shape.rs:429-462).  First every shadow
-    // ray (only the point is live across the traversals), then the Phong terms with the rest of the record.
-    unsigned long long shadow_mask = 0ull;  // <= 64 lights (checked at scene creation)
-    for (int l = 0; l < S.n_lights; l++) {
-      const double* LG = S.lights + 6 * l;
-      double vx = LG[3] - px, vy = LG[4] - py, vz = LG[5] - pz;
-      double distance = sqrt(vx * vx + vy * vy + vz * vz);
-      Ray sray;
-      sray.ox = px; sray.oy = py; sray.oz = pz;
-      sray.dx = vx / distance; sray.dy = vy / distance; sray.dz = vz / distance;
-      n_shadow++;
-      Trav Sh;
-      reset_closest(Sh, S.all_cast_shadow ? MODE_SHADOW_ANY : MODE_SHADOW_CLOSEST);
-      if (S.all_cast_shadow) Sh.thi = distance;
-      traverse<FEAT>(S, sray, Sh, C, stack, stride);
-      bool shadowed;
-      if (S.all_cast_shadow) shadowed = Sh.shadowed != 0;
-      else shadowed = (Sh.best_prim != 0x7fffffff) && (S.prims[Sh.best_prim].flags & 1u) && (Sh.best_t < distance);
-      if (shadowed) shadow_mask |= 1ull << l;
-    }
-    const double ex = r[3 * cap + s], ey = r[4 * cap + s], ez = r[5 * cap + s];
-    const double nx = r[6 * cap + s], ny = r[7 * cap + s], nz = r[8 * cap + s];
-    const double cr = r[9 * cap + s], cg = r[10 * cap + s], cbl = r[11 * cap + s];
-    const double* M = S.mat + 8 * W.sr_mat[s];
-    const double ambient = M[0], diffuse = M[1], specular = M[2], shininess = M[3];
-    double sr = 0.0, sg = 0.0, sb = 0.0;
-    for (int l = 0; l < S.n_lights; l++) {
-      const double* LG = S.lights + 6 * l;
-      double vx = LG[3] - px, vy = LG[4] - py, vz = LG[5] - pz;
-      double distance = sqrt(vx * vx + vy * vy + vz * vz);
-      const double ldx = vx / distance, ldy = vy / distance, ldz = vz / distance;  // the shadow ray's direction again
-      const bool shadowed = (shadow_mask >> l) & 1ull;
-      double er = cr * LG[0], eg = cg * LG[1], eb = cbl * LG[2];  // effective_color
-      double lr = er * ambient, lg = eg * ambient, lb = eb * ambient;
-      // light vector: (light.origin - point).normalize() — same numbers as the shadow ray direction
-      double ldn = ldx * nx + ldy * ny + ldz * nz;
-      double dr = 0.0, dg = 0.0, db = 0.0, pr = 0.0, pg = 0.0, pb = 0.0;
-      if (!shadowed && ldn >= 0.0) {
-        dr = er * diffuse * ldn; dg = eg * diffuse * ldn; db = eb * diffuse * ldn;
-        // reflect = (-light).reflect(normal)
-        double mlx = -ldx, mly = -ldy, mlz = -ldz;
-        double d2 = 2.0 * (mlx * nx + mly * ny + mlz * nz);
-        double rfx = mlx - nx * d2, rfy = mly - ny * d2, rfz = mlz - nz * d2;
-        double rde = rfx * ex + rfy * ey + rfz * ez;
-        if (rde > 0.0) {
-          double f = pow(rde, shininess);
-          pr = LG[0] * specular * f; pg = LG[1] * specular * f; pb = LG[2] * specular * f;
-        }
+  unsigned n_rays = 0, n_container = 0, n_shadow = 0;
+  const WorkMap wm = make_workmap(pm, cam);
+  const unsigned nt = tl >= 0 ? wf_count(W, tl, n0) : 0u;
+  unsigned ns = sl >= 0 ? W.counts[RTC_WF_SHADE_COUNT + sl] : 0u;
+  if (ns > W.cap) ns = W.cap;
+  const unsigned ct = (nt + RTC_WF_CHUNK - 1) / RTC_WF_CHUNK, cs = (ns + RTC_WF_CHUNK - 1) / RTC_WF_CHUNK;
+  const unsigned nx = gridDim.x < 8u ? gridDim.x : 8u;  // chunk residues in use (a grid smaller than 8 blocks has fewer)
+  const unsigned x = blockIdx.x % nx;
+  unsigned* next = &W.counts[RTC_WF_CHUNK_NEXT + 8 * slot + (int)x];
+  const int lane = RTC_LANE_ID;
+  for (;;) {
+    unsigned kx = 0;
+    if (lane == 0) kx = atomicAdd(next, 1u);
+    kx = __shfl(kx, 0);
+    const unsigned long long chunk = (unsigned long long)kx * nx + x;
+    if (chunk >= (unsigned long long)ct + cs) break;
+    if (chunk < ct) {
+      const unsigned base = (unsigned)chunk * RTC_WF_CHUNK;
+      for (unsigned o = 0; o < RTC_WF_CHUNK; o += RTC_WF_LANES) {
+        const unsigned i = base + o + (unsigned)lane;
+        if (i < nt) wf_trace_ray<FEAT>(S, cam, pm, W, wm, tl, i, hit_t, hit_prim, hit_k, stack, stride, C, n_rays, n_container);
       }
-      sr += (lr + dr) + pr; sg += (lg + dg) + pg; sb += (lb + db) + pb;
+    } else {
+      const unsigned base = (unsigned)(chunk - ct) * RTC_WF_CHUNK;
+      for (unsigned o = 0; o < RTC_WF_CHUNK; o += RTC_WF_LANES) {
+        const unsigned s = base + o + (unsigned)lane;
+        if (s < ns) wf_shadow_rec<FEAT>(S, W, sl, s, stack, stride, C, n_shadow);
+      }
     }
-    const double weight = r[12 * cap + s];
-    const int node = W.sr_node[s];
-    cb[node] = weight * sr; cb[cap + node] = weight * sg; cb[2 * cap + node] = weight * sb;
   }
   if (C.nan_ts) atomicAdd(&stats->nan_ts, (unsigned long long)C.nan_ts);
   if (COUNT) {
+    if (tl == 0) atomicAdd(&stats->rays_primary, (unsigned long long)n_rays);
+    atomicAdd(&stats->rays_container, (unsigned long long)n_container);
     atomicAdd(&stats->rays_shadow, (unsigned long long)n_shadow);
     atomicAdd(&stats->accel_nodes, (unsigned long long)C.accel_nodes);
     atomicAdd(&stats->group_tests, (unsigned long long)C.group_tests);
@@ -1547,27 +1569,31 @@ __global__ void __launch_bounds__(256) wf_reduce(DCamera cam, DPixelMap pm, DWav
 
 static inline unsigned rtc_stack_bytes(const DScene& S) { return (unsigned)S.bvh_stack * RTC_BLOCK * (unsigned)sizeof(int); }
 
-template <bool COUNT>
-static void launch_wf_t(int feat, const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, const DWave& W, unsigned n0, double* rgb, double* hit_t, int* hit_prim,
-                        int* hit_k, DStats* stats, hipStream_t stream, unsigned blocks) {
+template <bool COUNT, int FEAT>
+static void launch_wf_f(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, const DWave& W, unsigned n0, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
+                        DStats* stats, hipStream_t stream, unsigned blocks) {
   dim3 grid(blocks), block(RTC_BLOCK);
-  for (int level = 0; level <= fuel; level++) {
-    if (feat >= 3) hipLaunchKernelGGL((wf_trace<COUNT, 3>), grid, block, rtc_stack_bytes(S), stream, S, cam, pm, W, level, n0, hit_t, hit_prim, hit_k, stats);
-    else if (feat == 2) hipLaunchKernelGGL((wf_trace<COUNT, 2>), grid, block, rtc_stack_bytes(S), stream, S, cam, pm, W, level, n0, hit_t, hit_prim, hit_k, stats);
-    else if (feat == 1) hipLaunchKernelGGL((wf_trace<COUNT, 1>), grid, block, rtc_stack_bytes(S), stream, S, cam, pm, W, level, n0, hit_t, hit_prim, hit_k, stats);
-    else hipLaunchKernelGGL((wf_trace<COUNT, 0>), grid, block, rtc_stack_bytes(S), stream, S, cam, pm, W, level, n0, hit_t, hit_prim, hit_k, stats);
-    hipLaunchKernelGGL((wf_shade<COUNT>), dim3(std::max(1u, blocks * RTC_BLOCK / (unsigned)RTC_WF_SHADE_BLOCK / 4u)), dim3(RTC_WF_SHADE_BLOCK), 0, stream, S, cam, pm, W, level, n0, fuel, stats);
-    if (feat >= 3) hipLaunchKernelGGL((wf_shadow<COUNT, 3>), grid, block, rtc_stack_bytes(S), stream, S, W, level, stats);
-    else if (feat == 2) hipLaunchKernelGGL((wf_shadow<COUNT, 2>), grid, block, rtc_stack_bytes(S), stream, S, W, level, stats);
-    else if (feat == 1) hipLaunchKernelGGL((wf_shadow<COUNT, 1>), grid, block, rtc_stack_bytes(S), stream, S, W, level, stats);
-    else hipLaunchKernelGGL((wf_shadow<COUNT, 0>), grid, block, rtc_stack_bytes(S), stream, S, W, level, stats);
+  const dim3 sgrid(std::max(1u, blocks * RTC_BLOCK / (unsigned)RTC_WF_SHADE_BLOCK / 4u)), sblock(RTC_WF_SHADE_BLOCK);
+  // trace_0; shade_0; [shadow_0 + trace_1]; shade_1; ... [shadow_{fuel-1} + trace_fuel]; shade_fuel; shadow_fuel; sums
+  for (int level = 0; level <= fuel + 1; level++) {
+    const int tl = level <= fuel ? level : -1, sl = level - 1;
+    hipLaunchKernelGGL((wf_ts<COUNT, FEAT>), grid, block, rtc_stack_bytes(S), stream, S, cam, pm, W, tl, sl, n0, level, hit_t, hit_prim, hit_k, stats);
+    if (level <= fuel) hipLaunchKernelGGL((wf_shade<COUNT>), sgrid, sblock, 0, stream, S, cam, pm, W, level, n0, fuel, stats);
   }
   for (int level = fuel; level >= 0; level--)
     hipLaunchKernelGGL(wf_reduce, dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, stream, cam, pm, W, level, level == fuel ? 1 : 0, n0, rgb);
 }
+template <bool COUNT>
+static void launch_wf_t(int feat, const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, const DWave& W, unsigned n0, double* rgb, double* hit_t, int* hit_prim,
+                        int* hit_k, DStats* stats, hipStream_t stream, unsigned blocks) {
+  if (feat >= 3) launch_wf_f<COUNT, 3>(S, cam, pm, fuel, W, n0, rgb, hit_t, hit_prim, hit_k, stats, stream, blocks);
+  else if (feat == 2) launch_wf_f<COUNT, 2>(S, cam, pm, fuel, W, n0, rgb, hit_t, hit_prim, hit_k, stats, stream, blocks);
+  else if (feat == 1) launch_wf_f<COUNT, 1>(S, cam, pm, fuel, W, n0, rgb, hit_t, hit_prim, hit_k, stats, stream, blocks);
+  else launch_wf_f<COUNT, 0>(S, cam, pm, fuel, W, n0, rgb, hit_t, hit_prim, hit_k, stats, stream, blocks);
+}
 
-// One frame through the wavefront kernels.  The caller zeroed W.counts on the same stream and sized the arrays for
-// W.cap >= the work ids of the launch and fuel + 1 levels; `blocks` = grid size of the per-level kernels.
+// One frame through the wavefront kernels.  The caller zeroed W.counts (RTC_WF_COUNTS entries) on the stream and sized the
+// arrays for W.cap >= the work ids of the launch and fuel + 1 levels; `blocks` = grid size of the traversal kernels.
 void rtc_launch_wavefront(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, const DWave& W, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
                           DStats* stats, bool count, hipStream_t stream, unsigned blocks) {
   if (pm.n == 0) return;

@@ -110,8 +110,8 @@ int ensure_wave(rtc_scene* s, uint64_t n_work, int fuel) {
   HIP_OK(hipStreamSynchronize(s->stream));
   if (s->wave_mem) (void)hipFree(s->wave_mem);
   s->wave_mem = nullptr; s->wave_cap = 0; s->wave_levels = 0;
-  const uint64_t n_double = cap * (uint64_t)(7 + 7 + 1 + 2 + 13 + 3 * lv);
-  const uint64_t n_int = cap * (uint64_t)(1 + 1 + 1 + 2 * lv) + 64;
+  const uint64_t n_double = cap * (uint64_t)(7 + 7 + 1 + 2 + 13 + 13 + 3 * lv);
+  const uint64_t n_int = cap * (uint64_t)(1 + 2 + 2 + 2 * lv) + RTC_WF_COUNTS;
   HIP_OK(hipMalloc(&s->wave_mem, n_double * sizeof(double) + n_int * sizeof(int32_t)));
   double* d = (double*)s->wave_mem;
   DWave& W = s->wave;
@@ -119,12 +119,15 @@ int ensure_wave(rtc_scene* s, uint64_t n_work, int fuel) {
   W.rq[1] = d; d += 7 * cap;
   W.h_t = d; d += cap;
   W.h_n12 = d; d += 2 * cap;
-  W.sr = d; d += 13 * cap;
+  W.sr[0] = d; d += 13 * cap;
+  W.sr[1] = d; d += 13 * cap;
   W.contrib = d; d += 3 * (uint64_t)lv * cap;
   int32_t* q = (int32_t*)d;
   W.h_prim = q; q += cap;
-  W.sr_mat = q; q += cap;
-  W.sr_node = q; q += cap;
+  W.sr_mat[0] = q; q += cap;
+  W.sr_mat[1] = q; q += cap;
+  W.sr_node[0] = q; q += cap;
+  W.sr_node[1] = q; q += cap;
   W.child = q; q += 2 * (uint64_t)lv * cap;
   W.counts = (uint32_t*)q;
   W.cap = (uint32_t)cap;
@@ -149,7 +152,7 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
   if (wavefront) {
     int rc = ensure_wave(s, rtc_wavefront_work(cam, pm), fuel);
     if (rc != RTC_OK) return rc;
-    HIP_OK(hipMemsetAsync(s->wave.counts, 0, 64 * sizeof(uint32_t), s->stream));
+    HIP_OK(hipMemsetAsync(s->wave.counts, 0, RTC_WF_COUNTS * sizeof(uint32_t), s->stream));
     HIP_OK(hipEventRecord(s->ev0, s->stream));
     rtc_launch_wavefront(s->d, cam, pm, fuel, s->wave, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream, s->wave_blocks);
   } else if (s->kernel_version != 3) {

@@ -35,13 +35,13 @@ static int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double*
     const uint64_t n_work = rtc_wavefront_work(cam, pm);
     const uint64_t cap = std::max<uint64_t>(2 * n_work, 256);
     const int lv = fuel + 1;
-    std::vector<double> dd(cap * (uint64_t)(7 + 7 + 1 + 2 + 13 + 3 * lv));
-    std::vector<int32_t> ii(cap * (uint64_t)(3 + 2 * lv) + 64);
+    std::vector<double> dd(cap * (uint64_t)(7 + 7 + 1 + 2 + 13 + 13 + 3 * lv));
+    std::vector<int32_t> ii(cap * (uint64_t)(5 + 2 * lv) + RTC_WF_COUNTS);
     DWave W{};
     double* d = dd.data();
-    W.rq[0] = d; d += 7 * cap; W.rq[1] = d; d += 7 * cap; W.h_t = d; d += cap; W.h_n12 = d; d += 2 * cap; W.sr = d; d += 13 * cap; W.contrib = d;
+    W.rq[0] = d; d += 7 * cap; W.rq[1] = d; d += 7 * cap; W.h_t = d; d += cap; W.h_n12 = d; d += 2 * cap; W.sr[0] = d; d += 13 * cap; W.sr[1] = d; d += 13 * cap; W.contrib = d;
     int32_t* q = ii.data();
-    W.h_prim = q; q += cap; W.sr_mat = q; q += cap; W.sr_node = q; q += cap; W.child = q; q += 2 * (uint64_t)lv * cap; W.counts = (uint32_t*)q;
+    W.h_prim = q; q += cap; W.sr_mat[0] = q; q += cap; W.sr_mat[1] = q; q += cap; W.sr_node[0] = q; q += cap; W.sr_node[1] = q; q += cap; W.child = q; q += 2 * (uint64_t)lv * cap; W.counts = (uint32_t*)q;
     W.cap = (uint32_t)cap;
     rtc_launch_wavefront(s->d, cam, pm, fuel, W, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr, 5);
     if (W.counts[RTC_WF_OVERFLOW]) {  // as the product does: render again with the one-kernel path

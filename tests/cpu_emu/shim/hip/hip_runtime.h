@@ -18,6 +18,9 @@ struct uint3_ { unsigned x, y, z; };
 struct float4 { float x, y, z, w; };
 struct int4 { int x, y, z, w; };
 typedef void* hipStream_t;
+typedef void* hipEvent_t;
+static inline int hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+static inline int hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 using std::fabs; using std::floor;
 // fminf/fmaxf/fabsf come from <cmath> (C functions, NaN-ignoring like the device versions)
 #define EMU_PLACEHOLDER
