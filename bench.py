@@ -168,6 +168,7 @@ def main():
         dist.all_reduce(rays_local)
     rays_total = float(rays_local.item())
 
+    path = dr.tune(args.fuel, rank, world_size, fg.n_rows, fg.tiles[0])  # untimed: both device paths measured once, faster one kept
     run_frames(args.warmup)
     dr.check()
     if world_size > 1:
@@ -207,7 +208,9 @@ def main():
                        "unique_rays_per_frame": rays_total, "rays_per_pixel": rays_total / (H * V)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.workload)[0] if world_size == 1 else None, "traffic_source": pmc_traffic(args.workload)[1],
-                         "kernel": "rtc_trace_kernel", "kernel_ms_avg": avg_kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel": ("wavefront frame = wf_ts x%d + wf_shade x%d + wf_gather (dominant: wf_ts)" % (args.fuel + 2, args.fuel + 1))
+                                   if path["path"] == "wavefront" else "rtc_trace_kernel",
+                         "kernel_ms_avg": avg_kernel_ms, "path": path, "algorithmic_bytes_per_launch": alg_bytes,
                          "counters_rank0": {k: cst[k] for k in ("pixels", "unique_rays", "accel_nodes", "group_tests", "tri_tests", "analytic_tests", "rays_container")},
                          "note": "scene (%d B) is L2/Infinity-Cache resident; real HBM traffic ~ framebuffer only (SURVEY.md §8d)" % dr.info()["scene_device_bytes"]},
             "accelerator": dr.info(),
@@ -220,10 +223,10 @@ def main():
                 dr2 = DeviceRenderer(hip, nw2, c2, device=local_rank)
                 t2 = torch.zeros(c2.vsize * c2.hsize * 3, dtype=torch.float64, device=dev)
                 s2 = dr2.render_rows(args.fuel, 0, 1, c2.vsize, t2, count=True)
-                ms = [dr2.render_rows(args.fuel, 0, 1, c2.vsize, t2)["kernel_ms"] for _ in range(5)]
-                ms = sum(ms[1:]) / len(ms[1:])
+                ms = [dr2.render_rows(args.fuel, 0, 1, c2.vsize, t2)["kernel_ms"] for _ in range(6)]  # the first two measure the paths
+                ms = sum(ms[2:]) / len(ms[2:])
                 extra[name] = {"workload": d2, "mrays_per_s_kernel": s2["unique_rays"] / ms / 1e3, "kernel_ms": ms, "unique_rays": s2["unique_rays"],
-                               "roofline_achieved_GBs": algorithmic_bytes(s2) / (ms * 1e-3) / 1e9, "accelerator": dr2.info()}
+                               "roofline_achieved_GBs": algorithmic_bytes(s2) / (ms * 1e-3) / 1e9, "accelerator": dr2.info(), "path": dr2.path_info()}
             out["extra"] = extra
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(world, cam, args.fuel)

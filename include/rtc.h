@@ -190,9 +190,18 @@ int rtc_scene_elapsed_ms(rtc_scene*, int slot_from, int slot_to, double* ms);
 /* Blocks until the scene's stream is idle. */
 int rtc_scene_sync(rtc_scene*);
 
-/* Accelerator facts for reports: traversal-program length, BVH node count (64 B each), triangles packed into
- * mesh BVH leaves, deepest BVH.  Any pointer may be NULL. */
+/* Accelerator facts for reports: traversal-program length, BVH node count (4-wide nodes, 128 B each), triangles packed
+ * into mesh BVH leaves, deepest BVH (levels of 4-wide nodes).  Any pointer may be NULL. */
 void rtc_scene_accel_info(const rtc_scene*, uint32_t* n_ops, uint32_t* n_bvh_nodes, uint32_t* n_mesh_tris, uint32_t* bvh_depth);
+
+/* Which device path renders whole-row launches of this scene (both give bit-identical pixels and hits):
+ *   1  one kernel: a lane walks its pixel's whole ray tree (rtc_trace_kernel);
+ *   4  wavefront: per bounce level a closest-hit + shadow kernel and a shading kernel over ray queues (wf_* kernels).
+ * With the environment variable RTC_KERNEL unset the library measures: for one launch shape (camera, rows, fuel) the first
+ * two SYNCHRONOUS launches run one path each, every later launch of that shape takes the faster.  Reports the state for
+ * the most recent launch shape: *choice = 0 while undecided, else 1 or 4; the measured device times in ms (< 0 = not yet
+ * measured).  Any pointer may be NULL. */
+void rtc_scene_path_info(const rtc_scene*, int32_t* choice, double* one_kernel_ms, double* wavefront_ms);
 
 #ifdef __cplusplus
 }

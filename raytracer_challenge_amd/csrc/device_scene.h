@@ -170,9 +170,12 @@ struct DStats {  // device-side counters (atomically accumulated per wave)
 // fixed order afterwards, so a pixel's value does not depend on what else was rendered with it.
 #define RTC_WF_SHADE_COUNT 32  // counts[RTC_WF_SHADE_COUNT + level] = shade records of the level
 #define RTC_WF_OVERFLOW 63     // counts[RTC_WF_OVERFLOW] != 0: a queue overflowed, the frame must be rendered by the one-kernel path
-#define RTC_WF_CHUNK_NEXT 64   // counts[RTC_WF_CHUNK_NEXT + 8 * launch + xcd]: next chunk of traversal launch `launch` for blocks of that XCD
-#define RTC_WF_COUNTS 256
-#define RTC_WF_CHUNK 128u      // work items per chunk (two wave passes)
+#define RTC_WF_CHUNK_NEXT 64   // counts[RTC_WF_CHUNK_NEXT + 32 * (8 * launch + xcd)]: next chunk of traversal launch `launch` for blocks of
+                               // that XCD; one 128-byte line per cursor (same-line device atomics serialise)
+#define RTC_WF_COUNTS (64 + 32 * 8 * (RTC_MAX_FUEL + 2))
+#ifndef RTC_WF_CHUNK
+#define RTC_WF_CHUNK 64u       // work items per chunk: one wave pass (larger chunks leave waves idle at the small, deep levels: 256 -> +25 %)
+#endif
 struct DWave {
   double* rq[2];        // ray queues (level parity): 7 rows ox oy oz dx dy dz weight
   double* h_t;          // per ray of the level: closest hit t

@@ -58,6 +58,7 @@
 #define RTC_WF_LANES 64u
 #endif
 #define DINF (__builtin_inf())
+static inline unsigned rtc_stack_bytes(const DScene& S) { return (unsigned)S.bvh_stack * RTC_BLOCK * (unsigned)sizeof(int); }
 
 namespace {
 
@@ -1221,7 +1222,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, (FEAT >= 2 && RTC_WAVES_PER_SIMD < 
 //   wf_trace   closest hit (+ container pass for transparent hits) of every ray of the level
 //   wf_shade   hit state, pattern colour -> shade record; reflected / refracted rays -> the other queue
 //   wf_shadow  per shade record and light: shadow ray + Phong terms -> the ray's colour contribution
-//   wf_reduce  contribution[level] += contributions of its children in level + 1 (reflected first); level 0 writes rgb
+//   wf_gather  pixel = its ray tree's contributions, added in the one-kernel path's order (bit-identical results)
 // Every kernel is a grid-stride loop over a count that lives in device memory, so a frame is enqueued without host syncs.
 // =================================================================================================================
 namespace {
@@ -1508,7 +1509,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, FEAT <= 1 ? 4 : 2) wf_ts(DScene S, 
   const unsigned ct = (nt + RTC_WF_CHUNK - 1) / RTC_WF_CHUNK, cs = (ns + RTC_WF_CHUNK - 1) / RTC_WF_CHUNK;
   const unsigned nx = gridDim.x < 8u ? gridDim.x : 8u;  // chunk residues in use (a grid smaller than 8 blocks has fewer)
   const unsigned x = blockIdx.x % nx;
-  unsigned* next = &W.counts[RTC_WF_CHUNK_NEXT + 8 * slot + (int)x];
+  unsigned* next = &W.counts[RTC_WF_CHUNK_NEXT + 32 * (8 * slot + (int)x)];
   const int lane = RTC_LANE_ID;
   for (;;) {
     unsigned kx = 0;
@@ -1542,32 +1543,33 @@ __global__ void __launch_bounds__(RTC_BLOCK, FEAT <= 1 ? 4 : 2) wf_ts(DScene S, 
   }
 }
 
-// contribution[level][i] += contribution[level + 1][reflected child] + contribution[level + 1][refracted child], in that order;
-// at level 0 the sum is the pixel (rgb != nullptr).  last = the deepest level (no children to add).
-__global__ void __launch_bounds__(256) wf_reduce(DCamera cam, DPixelMap pm, DWave W, int level, int last, unsigned n0, double* __restrict__ rgb) {
+// Pixel = the contributions of its ray tree added in the order the one-kernel path adds them (a ray, then its reflected
+// subtree, then its refracted subtree: rtc_trace_kernel's depth-first loop), so both paths produce the same bits and a
+// pixel's value does not depend on what else was rendered with it.  One lane per level-0 work id walks the child links.
+__global__ void __launch_bounds__(256) wf_gather(DCamera cam, DPixelMap pm, DWave W, unsigned n0, double* __restrict__ rgb) {
   const WorkMap wm = make_workmap(pm, cam);
-  const unsigned count = wf_count(W, level, n0);
   const size_t cap = W.cap;
-  double* cb = W.contrib + (size_t)level * 3 * cap;
-  const double* nb = W.contrib + (size_t)(level + 1) * 3 * cap;
-  const int32_t* ch = W.child + (size_t)level * 2 * cap;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-    double r = cb[i], g = cb[cap + i], b = cb[2 * cap + i];
-    if (!last) {
-      const int a = ch[i], c = ch[cap + i];
-      if (a >= 0) { r += nb[a]; g += nb[cap + a]; b += nb[2 * cap + a]; }
-      if (c >= 0) { r += nb[c]; g += nb[cap + c]; b += nb[2 * cap + c]; }
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n0; i += gridDim.x * blockDim.x) {
+    uint64_t q;
+    if (!work_to_slot(wm, i, q)) continue;
+    double r = 0.0, g = 0.0, b = 0.0;
+    int wait_idx[RTC_MAX_FUEL + 1];  // refracted children waiting for their turn; entry k belongs to level wait_lvl[k]
+    int wait_lvl[RTC_MAX_FUEL + 1];
+    int sp = 0, lvl = 0, idx = (int)i;
+    for (;;) {
+      const double* cb = W.contrib + (size_t)lvl * 3 * cap;
+      const int32_t* ch = W.child + (size_t)lvl * 2 * cap;
+      r += cb[idx]; g += cb[cap + idx]; b += cb[2 * cap + idx];
+      const int a = ch[idx], c = ch[cap + idx];
+      if (c >= 0) { wait_idx[sp] = c; wait_lvl[sp] = lvl + 1; sp++; }
+      if (a >= 0) { idx = a; lvl++; continue; }
+      if (sp == 0) break;
+      sp--;
+      idx = wait_idx[sp]; lvl = wait_lvl[sp];
     }
-    if (level == 0) {
-      uint64_t q;
-      if (work_to_slot(wm, i, q)) { rgb[3 * q + 0] = r; rgb[3 * q + 1] = g; rgb[3 * q + 2] = b; }
-    } else {
-      cb[i] = r; cb[cap + i] = g; cb[2 * cap + i] = b;
-    }
+    rgb[3 * q + 0] = r; rgb[3 * q + 1] = g; rgb[3 * q + 2] = b;
   }
 }
-
-static inline unsigned rtc_stack_bytes(const DScene& S) { return (unsigned)S.bvh_stack * RTC_BLOCK * (unsigned)sizeof(int); }
 
 template <bool COUNT, int FEAT>
 static void launch_wf_f(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, const DWave& W, unsigned n0, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
@@ -1580,8 +1582,8 @@ static void launch_wf_f(const DScene& S, const DCamera& cam, const DPixelMap& pm
     hipLaunchKernelGGL((wf_ts<COUNT, FEAT>), grid, block, rtc_stack_bytes(S), stream, S, cam, pm, W, tl, sl, n0, level, hit_t, hit_prim, hit_k, stats);
     if (level <= fuel) hipLaunchKernelGGL((wf_shade<COUNT>), sgrid, sblock, 0, stream, S, cam, pm, W, level, n0, fuel, stats);
   }
-  for (int level = fuel; level >= 0; level--)
-    hipLaunchKernelGGL(wf_reduce, dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, stream, cam, pm, W, level, level == fuel ? 1 : 0, n0, rgb);
+  (void)fuel;
+  hipLaunchKernelGGL(wf_gather, dim3(std::max(1u, std::min(blocks, (n0 + 255u) / 256u))), dim3(256), 0, stream, cam, pm, W, n0, rgb);
 }
 template <bool COUNT>
 static void launch_wf_t(int feat, const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, const DWave& W, unsigned n0, double* rgb, double* hit_t, int* hit_prim,

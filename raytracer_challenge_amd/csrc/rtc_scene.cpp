@@ -56,7 +56,11 @@ struct rtc_scene {
   uint64_t* d_idx = nullptr;
   double* d_rays = nullptr;
   uint64_t cap_px = 0, cap_idx = 0, cap_rays = 0;
-  int kernel_version = 1;
+  int kernel_version = 0;  // 0: measured choice between the one-kernel (1) and the wavefront (4) path, per launch signature
+  uint64_t tune_sig = 0;
+  double tune_ms[2] = {-1.0, -1.0};
+  int tune_choice = 0;
+  bool last_wavefront = false;
   unsigned long long* d_next = nullptr;  // work counter of the refill variant (RTC_KERNEL=3)
   unsigned max_blocks_v3 = 0;
   // wavefront path (RTC_KERNEL=4): queues and per-level arrays, grown on demand
@@ -142,20 +146,49 @@ void to_dcam(const rtc_camera& c, DCamera* d) {
   std::memcpy(d->inv, c.transform_inv, sizeof(d->inv));
 }
 
-int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb, bool want_hits, rtc_stats* stats, bool count, bool sync) {
+// Signature of a launch for the path choice below: everything the ray counts of a frame depend on besides the scene.
+uint64_t launch_signature(const DCamera& cam, const DPixelMap& pm, int fuel) {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](const void* p, size_t n) { for (size_t i = 0; i < n; i++) { h ^= ((const unsigned char*)p)[i]; h *= 1099511628211ull; } };
+  mix(&cam, sizeof(cam));
+  mix(&pm.n, sizeof(pm.n)); mix(&pm.mode, sizeof(pm.mode)); mix(&pm.row_first, sizeof(pm.row_first)); mix(&pm.row_step, sizeof(pm.row_step));
+  mix(&fuel, sizeof(fuel));
+  return h ? h : 1;
+}
+
+// Which path renders a launch (RTC_KERNEL unset).  The one-kernel path wins on cheap frames (few bounces, ~1 ms), the
+// wavefront path on deep ray trees (config 2: 1.6x); which one depends on scene, camera and fuel, so the choice is
+// measured: for a given launch signature the first two synchronous launches run one path each and every later launch
+// (synchronous or not) takes the faster.  Until then: a guess from the materials and the launch size.  A wavefront launch
+// whose queues overflowed is rendered again by the one-kernel path and never chosen for that signature, so an
+// unsynchronised wavefront launch only ever repeats a launch that is known to fit.
+int pick_path(rtc_scene* s, uint64_t sig, uint64_t n_work, bool will_sync, bool pixel_list) {
+  if (sig != s->tune_sig) { s->tune_sig = sig; s->tune_ms[0] = s->tune_ms[1] = -1.0; s->tune_choice = 0; }
+  if (pixel_list) return 1;  // index lists and explicit rays: small, irregular launches
+  if (s->tune_choice) return s->tune_choice;
+  if (will_sync) return s->tune_ms[1] < 0.0 ? 4 : (s->tune_ms[0] < 0.0 ? 1 : 4);
+  return 1;
+}
+
+int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb, bool want_hits, rtc_stats* stats, bool count, bool sync, int force = 0) {
   if (fuel < 0) fuel = 0;  // fuel <= 0 spawns nothing (src/world.rs:90,110)
   if (fuel > RTC_MAX_FUEL) return rtc_fail(RTC_ERR_INVALID, "fuel exceeds RTC_MAX_FUEL");
   HIP_OK(hipSetDevice(s->device));
   HIP_OK(hipMemsetAsync(s->d_stats, 0, sizeof(DStats), s->stream));
   HIP_OK(hipEventRecord(s->ev0, s->stream));
-  bool wavefront = s->kernel_version == 4 && pm.n > 0;
+  const bool will_sync = sync || stats != nullptr;
+  const bool tuned = force == 0 && s->kernel_version == 0;
+  int path = force ? force : s->kernel_version;
+  if (tuned) path = pick_path(s, launch_signature(cam, pm, fuel), rtc_wavefront_work(cam, pm), will_sync, pm.mode != 2);
+  const bool wavefront = path == 4 && pm.n > 0;
+  s->last_wavefront = wavefront;
   if (wavefront) {
     int rc = ensure_wave(s, rtc_wavefront_work(cam, pm), fuel);
     if (rc != RTC_OK) return rc;
     HIP_OK(hipMemsetAsync(s->wave.counts, 0, RTC_WF_COUNTS * sizeof(uint32_t), s->stream));
     HIP_OK(hipEventRecord(s->ev0, s->stream));
     rtc_launch_wavefront(s->d, cam, pm, fuel, s->wave, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream, s->wave_blocks);
-  } else if (s->kernel_version != 3) {
+  } else if (path != 3) {
     rtc_launch_trace(s->d, cam, pm, fuel, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream, 0, s->d_next);
   } else {
     // persistent v1 with per-lane refill: the work counter starts after the ids the grid's lanes take implicitly
@@ -175,12 +208,15 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
     uint32_t overflow = 0;
     HIP_OK(hipMemcpy(&overflow, s->wave.counts + RTC_WF_OVERFLOW, sizeof(overflow), hipMemcpyDeviceToHost));
     if (overflow) {  // a level outgrew its queue: render the launch again with the one-kernel path (always fits)
-      const int kv = s->kernel_version;
-      s->kernel_version = 1;
-      int rc = run(s, cam, pm, fuel, d_rgb, want_hits, stats, count, true);
-      s->kernel_version = kv;
-      return rc;
+      if (tuned) { s->tune_ms[1] = 1e30; s->tune_choice = 1; }
+      return run(s, cam, pm, fuel, d_rgb, want_hits, stats, count, true, 1);
     }
+  }
+  if (tuned && !count && pm.mode == 2 && !s->tune_choice) {
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    s->tune_ms[wavefront ? 1 : 0] = ms;
+    if (s->tune_ms[0] >= 0.0 && s->tune_ms[1] >= 0.0) s->tune_choice = s->tune_ms[1] < s->tune_ms[0] ? 4 : 1;
   }
   DStats h;
   HIP_OK(hipMemcpy(&h, s->d_stats, sizeof(h), hipMemcpyDeviceToHost));
@@ -294,7 +330,8 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     // 8x8 tiles; 3 = persistent grid, lanes refill from a global work counter.  (2 was a persistent state machine with voted
     // step kinds: 2.6x slower than 1 on every configuration, removed)
     const char* kv = std::getenv("RTC_KERNEL");
-    s->kernel_version = (kv && std::atoi(kv) == 3) ? 3 : ((kv && std::atoi(kv) == 4) ? 4 : 1);
+    const int kvi = kv ? std::atoi(kv) : 0;
+    s->kernel_version = (kvi == 1 || kvi == 3 || kvi == 4) ? kvi : 0;
     // hipDeviceGetAttribute, not hipGetDeviceProperties: the property struct's layout differs between ROCm releases and
     // this library may run on the HIP runtime PyTorch loaded first.
     int n_cu = 0;
@@ -302,7 +339,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     int per_cu3 = rtc_v3_blocks_per_cu();
     if (const char* w = std::getenv("RTC_V3_BLOCKS_PER_CU")) per_cu3 = std::max(1, std::atoi(w));
     s->max_blocks_v3 = (unsigned)std::max(1, n_cu * per_cu3);
-    s->wave_blocks = (unsigned)std::max(1, n_cu * 64);
+    s->wave_blocks = (unsigned)std::max(1, n_cu * 32);
     if (const char* w = std::getenv("RTC_WF_BLOCKS_PER_CU")) s->wave_blocks = (unsigned)std::max(1, n_cu * std::atoi(w));
   }
   *out = s.release();
@@ -518,7 +555,7 @@ int rtc_scene_check(rtc_scene* s) {
   HIP_OK(hipMemcpy(&h, s->d_stats, sizeof(h), hipMemcpyDeviceToHost));
   if (h.guard) return rtc_fail(RTC_ERR_DEVICE, "traversal guard tripped (mask " + std::to_string(h.guard) + ")");
   if (h.nan_ts) return rtc_fail(RTC_ERR_NAN, "a NaN intersection t was produced (the reference panics in Intersection::sort, src/intersection.rs:124)");
-  if (s->kernel_version == 4 && s->wave_mem) {
+  if (s->last_wavefront && s->wave_mem) {
     uint32_t overflow = 0;
     HIP_OK(hipMemcpy(&overflow, s->wave.counts + RTC_WF_OVERFLOW, sizeof(overflow), hipMemcpyDeviceToHost));
     if (overflow) return rtc_fail(RTC_ERR_UNSUPPORTED, "a wavefront ray queue overflowed in an unsynchronised launch: render this launch synchronously (falls back by itself)");
@@ -554,6 +591,12 @@ int rtc_scene_sync(rtc_scene* s) {
 }
 
 // Accelerator facts for reports (not part of the reference-facing surface).
+void rtc_scene_path_info(const rtc_scene* s, int32_t* choice, double* one_kernel_ms, double* wavefront_ms) {
+  if (choice) *choice = s ? (s->kernel_version ? s->kernel_version : s->tune_choice) : 0;
+  if (one_kernel_ms) *one_kernel_ms = s ? s->tune_ms[0] : -1.0;
+  if (wavefront_ms) *wavefront_ms = s ? s->tune_ms[1] : -1.0;
+}
+
 void rtc_scene_accel_info(const rtc_scene* s, uint32_t* n_ops, uint32_t* n_bvh_nodes, uint32_t* n_mesh_tris, uint32_t* bvh_depth) {
   if (n_ops) *n_ops = s ? (uint32_t)s->d.n_ops : 0;
   if (n_bvh_nodes) *n_bvh_nodes = s ? s->n_bvh_nodes : 0;

@@ -30,7 +30,7 @@ class RtcStatsC(C.Structure):
 
 # algorithmic bytes per unit of work
 BYTES_RAY = 64 + 32          # ray in + hit out
-BYTES_NODE = 64              # accelerator node / reference group box
+BYTES_NODE = 128             # 4-wide accelerator node (a reference group box test is charged the same)
 BYTES_TRI = 72               # p1, e1, e2 (f64)
 BYTES_ANALYTIC = 112         # 3x4 f64 matrix + params
 BYTES_PIXEL = 24             # framebuffer write (3 x f64)
@@ -121,6 +121,22 @@ class DeviceRenderer:
 
     def sync(self):
         self.backend.lib.rtc_scene_sync(self.scene)
+
+    def tune(self, fuel: int, row_first: int, row_step: int, n_rows: int, out_tensor) -> dict:
+        """Lets the library measure both device paths for this launch shape (two synchronous renders into out_tensor) so
+        that later launches, including unsynchronised ones, take the faster; returns path_info()."""
+        for _ in range(2):
+            self.render_rows(fuel, row_first, row_step, n_rows, out_tensor, count=False, sync=True, want_stats=False)
+        return self.path_info()
+
+    def path_info(self) -> dict:
+        lib = self.backend.lib
+        lib.rtc_scene_path_info.restype = None
+        lib.rtc_scene_path_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        ch, a, b = C.c_int32(0), C.c_double(-1), C.c_double(-1)
+        lib.rtc_scene_path_info(self.scene, C.byref(ch), C.byref(a), C.byref(b))
+        return {"path": {0: "undecided", 1: "one kernel", 3: "one kernel, refill", 4: "wavefront"}.get(ch.value, str(ch.value)),
+                "one_kernel_ms": a.value, "wavefront_ms": b.value}
 
     def info(self) -> dict:
         a = [C.c_uint32(0) for _ in range(4)]

@@ -5,16 +5,16 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 for feat in (sys.argv[2:] or ["0", "1"]):
-    idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("void wf_trace<false, %s>" % feat)]
+    idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("void wf_ts<false, %s>" % feat)]
     if not idx:
         continue
-    # frames are separated by a wf_reduce run; take the last complete frame
+    # frames are separated by a wf_gather run; take the last complete frame
     last = idx[-1]
     start = last
-    while start > 0 and not rows[start - 1]["Kernel_Name"].startswith("wf_reduce"):
+    while start > 0 and not rows[start - 1]["Kernel_Name"].startswith("wf_gather"):
         start -= 1
     end = last
-    while end + 1 < len(rows) and (rows[end + 1]["Kernel_Name"].startswith("void wf_") or rows[end + 1]["Kernel_Name"].startswith("wf_reduce")):
+    while end + 1 < len(rows) and (rows[end + 1]["Kernel_Name"].startswith("void wf_") or rows[end + 1]["Kernel_Name"].startswith("wf_gather")):
         end += 1
     t0 = int(rows[start]["Start_Timestamp"])
     print("== feature level %s: %d kernels, %.1f us" % (feat, end - start + 1, (int(rows[end]["End_Timestamp"]) - t0) / 1e3))

@@ -123,6 +123,12 @@ int rtc_scene_check(rtc_scene*) { return RTC_OK; }
 int rtc_scene_record(rtc_scene*, int) { return RTC_OK; }
 int rtc_scene_wait(rtc_scene*, int) { return RTC_OK; }
 int rtc_scene_elapsed_ms(rtc_scene*, int, int, double* ms) { if (ms) *ms = 0.0; return RTC_OK; }
+void rtc_scene_path_info(const rtc_scene*, int32_t* choice, double* one_kernel_ms, double* wavefront_ms) {
+  const char* kv = std::getenv("RTC_KERNEL");
+  if (choice) *choice = kv ? std::atoi(kv) : 1;
+  if (one_kernel_ms) *one_kernel_ms = -1.0;
+  if (wavefront_ms) *wavefront_ms = -1.0;
+}
 void rtc_scene_accel_info(const rtc_scene* s, uint32_t* n_ops, uint32_t* n_bvh_nodes, uint32_t* n_mesh_tris, uint32_t* bvh_depth) {
   if (n_ops) *n_ops = (uint32_t)s->H.ops.size();
   if (n_bvh_nodes) *n_bvh_nodes = (uint32_t)s->H.bvh.size();

@@ -41,6 +41,20 @@ def test_emulated_other_kernel_versions(emu, orc, version, monkeypatch):
         assert_parity(emu, orc, world, cam, 5, label="kernel v%s %s" % (version, name))
 
 
+def test_wavefront_and_one_kernel_paths_agree_bitwise(emu, monkeypatch):
+    """The wavefront path adds a pixel's contributions in the one-kernel path's order: same bits, whatever the path."""
+    for name in ("nested_glass", "synthetic_cones_grouped", "patterns_and_noise", "csg_scene"):
+        cam, world = cases.SMALL_CASES[name]()
+        out = {}
+        for version in ("1", "4"):
+            monkeypatch.setenv("RTC_KERNEL", version)
+            nw = emu.build_world(world)
+            rgb, hits = emu.render(nw, cam, 5)
+            out[version] = (rgb.copy(), hits.copy())
+        assert np.array_equal(out["1"][0], out["4"][0]), name
+        assert np.array_equal(out["1"][1], out["4"][1]), name
+
+
 @pytest.mark.parametrize("version", ["3", "4"])
 def test_simt_emulation(orc, version, monkeypatch):
     """One thread per lane: lanes share the block's stack array and race on the work counter (3); wave-aggregated queue
