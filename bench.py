@@ -56,13 +56,24 @@ def make_workload(name):
     return cam, world, desc
 
 
-def pmc_traffic(workload):
-    """HBM bytes per launch measured with rocprofv3 PMC passes for this workload (profiles/pmc_traffic.json), or None."""
+def pmc_traffic(workload, path):
+    """HBM bytes per launch (one-kernel path) / per frame (wavefront path) measured with rocprofv3 PMC passes for this
+    workload on the device path this run uses (profiles/pmc_traffic.json), or None."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[workload]
+        if ("wavefront" in t.get("path", "")) != (path == "wavefront"):
+            return None, None
         return t["fetch_bytes"] + t["write_bytes"], t["source"]
     except Exception:
         return None, None
+
+
+def capped_algorithmic_bytes(st, n_prims):
+    """the counted figure, never more than 4x the ideal one-descent figure (guards against a bad BVH)."""
+    import math
+    from raytracer_challenge_amd.device import algorithmic_bytes
+    ideal = 96 + 64 * math.ceil(math.log2(max(2, n_prims))) + 72 * 4
+    return min(algorithmic_bytes(st), 4 * ideal * st["unique_rays"] + 24 * st["pixels"])
 
 
 def cpu_threads():
@@ -193,7 +204,7 @@ def main():
 
     if rank == 0:
         avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
-        alg_bytes = algorithmic_bytes(cst)
+        alg_bytes = capped_algorithmic_bytes(cst, nw.primitive_count)
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "Mrays/s (unique rays: primary+shadow+reflection+refraction) at %dx%d depth-%d" % (H, V, args.fuel),
@@ -207,7 +218,7 @@ def main():
                        "partition": "rows interleaved by rank, RCCL gather to rank 0" if world_size > 1 else "single GPU",
                        "unique_rays_per_frame": rays_total, "rays_per_pixel": rays_total / (H * V)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.workload)[0] if world_size == 1 else None, "traffic_source": pmc_traffic(args.workload)[1],
+                         "traffic": pmc_traffic(args.workload, path["path"])[0] if world_size == 1 else None, "traffic_source": pmc_traffic(args.workload, path["path"])[1],
                          "kernel": ("wavefront frame = wf_ts x%d + wf_shade x%d + wf_gather (dominant: wf_ts)" % (args.fuel + 2, args.fuel + 1))
                                    if path["path"] == "wavefront" else "rtc_trace_kernel",
                          "kernel_ms_avg": avg_kernel_ms, "path": path, "algorithmic_bytes_per_launch": alg_bytes,
@@ -226,7 +237,7 @@ def main():
                 ms = [dr2.render_rows(args.fuel, 0, 1, c2.vsize, t2)["kernel_ms"] for _ in range(6)]  # the first two measure the paths
                 ms = sum(ms[2:]) / len(ms[2:])
                 extra[name] = {"workload": d2, "mrays_per_s_kernel": s2["unique_rays"] / ms / 1e3, "kernel_ms": ms, "unique_rays": s2["unique_rays"],
-                               "roofline_achieved_GBs": algorithmic_bytes(s2) / (ms * 1e-3) / 1e9, "accelerator": dr2.info(), "path": dr2.path_info()}
+                               "roofline_achieved_GBs": capped_algorithmic_bytes(s2, nw2.primitive_count) / (ms * 1e-3) / 1e9, "accelerator": dr2.info(), "path": dr2.path_info()}
             out["extra"] = extra
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(world, cam, args.fuel)

@@ -19,20 +19,30 @@ if os.path.exists(log):
             j = json.loads(line)
             print("\n## bench line of the profiled run (profiled clocks; not a headline number)")
             print(json.dumps({k: j[k] for k in ("value", "unit", "ms_per_step", "roofline")}))
-print("\n## PMC passes (per-dispatch mean over rtc_trace_kernel<false> dispatches; counting variant <true> excluded)")
+print("\n## PMC passes: one-kernel path = per-dispatch mean over rtc_trace_kernel<false>; wavefront path = per-FRAME sum over the")
+print("## wf_ts<false> / wf_shade<false> / wf_gather dispatches (frames = #wf_ts<false> - #wf_shade<false>); counting variants <true> excluded")
 for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     if not os.path.isdir(d):
         continue
     for f in sorted(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)[-1:]:
         acc, n = defaultdict(float), defaultdict(int)
+        wf, n_ts, n_shade, n_gather_all, n_count_frames = defaultdict(float), defaultdict(int), defaultdict(int), defaultdict(int), defaultdict(int)
         for row in csv.DictReader(open(f)):
-            kn = row.get("Kernel_Name", "")
-            if "rtc_trace_kernel<false" not in kn and "rtc_persist_kernel<false" not in kn:
-                continue
-            acc[row["Counter_Name"]] += float(row["Counter_Value"])
-            n[row["Counter_Name"]] += 1
+            kn, cn, v = row.get("Kernel_Name", ""), row["Counter_Name"], float(row["Counter_Value"])
+            if "rtc_trace_kernel<false" in kn:
+                acc[cn] += v
+                n[cn] += 1
+            elif "wf_ts<false" in kn or "wf_shade<false" in kn:
+                wf[cn] += v
+                if "wf_ts<false" in kn:
+                    n_ts[cn] += 1
+                else:
+                    n_shade[cn] += 1
         for k in sorted(acc):
-            print("%-32s mean/dispatch = %.6g   (dispatches %d)" % (k, acc[k] / n[k], n[k]))
+            print("%-32s one-kernel mean/dispatch = %.6g   (dispatches %d)" % (k, acc[k] / n[k], n[k]))
+        for k in sorted(wf):
+            frames = max(1, n_ts[k] - n_shade[k])
+            print("%-32s wavefront sum/frame (wf_ts + wf_shade) = %.6g   (frames %d, wf_ts dispatches %d)" % (k, wf[k] / frames, frames, n_ts[k]))
 err = os.path.join(out, "errors.txt")
 if os.path.exists(err):
     print("\n## errors\n" + open(err).read())
