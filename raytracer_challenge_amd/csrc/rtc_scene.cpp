@@ -69,6 +69,7 @@ struct rtc_scene {
   uint64_t wave_cap = 0;
   int wave_levels = 0;
   unsigned wave_blocks = 0;
+  unsigned wave_mul = 2;  // queue capacity per level, in multiples of the launch's level-0 work ids
   int bvh_depth = 0;
   uint32_t n_bvh_nodes = 0, n_mesh_tris = 0;
 
@@ -102,21 +103,27 @@ int ensure_px(rtc_scene* s, uint64_t n, bool hits) {
   return RTC_OK;
 }
 
-// Sizes the wavefront arrays for `n_work` level-0 work ids and fuel + 1 levels: every level may hold up to 2 n_work rays
-// (a level that needs more sets the overflow flag and the frame is rendered again by the one-kernel path).
+// Sizes the wavefront arrays for `n_work` level-0 work ids and fuel + 1 levels: every level may hold up to wave_mul x n_work
+// rays (2 to start with).  A level that needs more sets the overflow flag; a synchronous launch then doubles wave_mul and
+// renders again while the arrays stay under RTC_WF_MAX_BYTES (default 24 GiB), else falls back to the one-kernel path.
+uint64_t wave_bytes(uint64_t cap, int lv) {
+  return cap * (uint64_t)(7 + 7 + 1 + 2 + 13 + 13 + 3 * lv) * sizeof(double) + (cap * (uint64_t)(1 + 2 + 2 + 2 * lv) + RTC_WF_COUNTS) * sizeof(int32_t);
+}
+uint64_t wave_budget() {
+  const char* e = std::getenv("RTC_WF_MAX_BYTES");
+  return e ? std::strtoull(e, nullptr, 10) : (24ull << 30);
+}
 int ensure_wave(rtc_scene* s, uint64_t n_work, int fuel) {
   const int levels = fuel + 1;
-  uint64_t cap = std::max<uint64_t>(2 * n_work, 4096);
-  if (cap > 0x7fffff00ull) return rtc_fail(RTC_ERR_UNSUPPORTED, "launch too large for the wavefront path");
+  uint64_t cap = std::max<uint64_t>((uint64_t)s->wave_mul * n_work, 4096);
+  if (cap > 0x7fffff00ull || wave_bytes(cap, levels) > wave_budget()) return rtc_fail(RTC_ERR_UNSUPPORTED, "launch too large for the wavefront path");
   if (cap <= s->wave_cap && levels <= s->wave_levels) return RTC_OK;
   cap = std::max(cap, s->wave_cap);
   const int lv = std::max(levels, s->wave_levels);
   HIP_OK(hipStreamSynchronize(s->stream));
   if (s->wave_mem) (void)hipFree(s->wave_mem);
   s->wave_mem = nullptr; s->wave_cap = 0; s->wave_levels = 0;
-  const uint64_t n_double = cap * (uint64_t)(7 + 7 + 1 + 2 + 13 + 13 + 3 * lv);
-  const uint64_t n_int = cap * (uint64_t)(1 + 2 + 2 + 2 * lv) + RTC_WF_COUNTS;
-  HIP_OK(hipMalloc(&s->wave_mem, n_double * sizeof(double) + n_int * sizeof(int32_t)));
+  HIP_OK(hipMalloc(&s->wave_mem, wave_bytes(cap, lv)));
   double* d = (double*)s->wave_mem;
   DWave& W = s->wave;
   W.rq[0] = d; d += 7 * cap;
@@ -184,6 +191,10 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
   s->last_wavefront = wavefront;
   if (wavefront) {
     int rc = ensure_wave(s, rtc_wavefront_work(cam, pm), fuel);
+    if (rc == RTC_ERR_UNSUPPORTED && tuned) {  // does not fit the memory budget: this launch shape stays on the one-kernel path
+      s->tune_ms[1] = 1e30; s->tune_choice = 1;
+      return run(s, cam, pm, fuel, d_rgb, want_hits, stats, count, sync, 1);
+    }
     if (rc != RTC_OK) return rc;
     HIP_OK(hipMemsetAsync(s->wave.counts, 0, RTC_WF_COUNTS * sizeof(uint32_t), s->stream));
     HIP_OK(hipEventRecord(s->ev0, s->stream));
@@ -207,7 +218,12 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
   if (wavefront) {
     uint32_t overflow = 0;
     HIP_OK(hipMemcpy(&overflow, s->wave.counts + RTC_WF_OVERFLOW, sizeof(overflow), hipMemcpyDeviceToHost));
-    if (overflow) {  // a level outgrew its queue: render the launch again with the one-kernel path (always fits)
+    if (overflow) {  // a level outgrew its queue: larger queues if they fit the budget, else the one-kernel path (always fits)
+      const uint64_t n_work = rtc_wavefront_work(cam, pm);
+      if (s->wave_mul < 64 && wave_bytes(2ull * s->wave_mul * n_work, fuel + 1) <= wave_budget() && 2ull * s->wave_mul * n_work <= 0x7fffff00ull) {
+        s->wave_mul *= 2;
+        return run(s, cam, pm, fuel, d_rgb, want_hits, stats, count, true, 4);
+      }
       if (tuned) { s->tune_ms[1] = 1e30; s->tune_choice = 1; }
       return run(s, cam, pm, fuel, d_rgb, want_hits, stats, count, true, 1);
     }
