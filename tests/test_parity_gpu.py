@@ -90,6 +90,51 @@ def test_hip_rows_device_matches_host_path(hip):
         assert np.array_equal(got, want), (step, first)
 
 
+def test_hip_both_paths_give_the_same_bits(hip, monkeypatch):
+    """One-kernel path (RTC_KERNEL=1) and wavefront path (RTC_KERNEL=4): identical pixels and hit records, bit for bit
+    (the wavefront path adds a pixel's contributions in the one-kernel path's order)."""
+    for name in ("nested_glass", "synthetic_cones_grouped", "patterns_and_noise", "csg_scene", "teapot_low"):
+        cam, world = cases.SMALL_CASES[name]()
+        out = {}
+        for version in ("1", "4"):
+            monkeypatch.setenv("RTC_KERNEL", version)
+            nw = hip.build_world(world)
+            out[version] = hip.render(nw, cam, 5)
+        assert np.array_equal(out["1"][0], out["4"][0]), name
+        assert np.array_equal(out["1"][1], out["4"][1]), name
+
+
+def test_hip_wavefront_queue_growth_and_fallback(hip, orc, monkeypatch):
+    """A glass scene at fuel 8 outgrows the initial queues (2 x work ids per level): with the default memory budget the
+    queues grow and the wavefront path finishes; with a budget too small for any growth the launch falls back to the
+    one-kernel path.  Both must match the oracle."""
+    cam, world = cases.nested_glass()
+    monkeypatch.setenv("RTC_KERNEL", "4")
+    assert_parity(hip, orc, world, cam, 8, label="nested_glass fuel 8, queues grown")
+    monkeypatch.setenv("RTC_WF_MAX_BYTES", "4000000")
+    assert_parity(hip, orc, world, cam, 8, label="nested_glass fuel 8, fallback")
+
+
+def test_hip_measured_path_choice(hip):
+    """DeviceRenderer.tune(): two synchronous launches measure both paths, later launches (also unsynchronised ones) take
+    the faster; whatever is chosen, the pixels are those of a plain synchronous render."""
+    import torch
+    from raytracer_challenge_amd.device import DeviceRenderer
+    cam, world = scenes.synthetic_analytic(hsize=256, vsize=144)
+    nw = hip.build_world(world)
+    full, _ = hip.render(nw, cam, 5)
+    dr = DeviceRenderer(hip, nw, cam, device=0)
+    out = torch.empty(cam.vsize * cam.hsize * 3, dtype=torch.float64, device="cuda:0")
+    assert dr.path_info()["path"] == "undecided"
+    info = dr.tune(5, 0, 1, cam.vsize, out)
+    assert info["path"] in ("one kernel", "wavefront") and info["one_kernel_ms"] > 0 and info["wavefront_ms"] > 0
+    out.zero_()
+    dr.render_rows_async(5, 0, 1, cam.vsize, out)
+    dr.sync()
+    dr.check()
+    assert np.array_equal(out.cpu().numpy().reshape(-1, 3), full)
+
+
 def test_hip_config4_teapot_high_4k_fuel8(hip, orc):
     """BASELINE configs[3] on one GPU: teapot_high.obj (6 320 smooth triangles), 3840x2160, fuel 8 — full frame on the HIP path,
     a strided sample against the oracle (which tests every triangle of the flat group, src/shape.rs:254-256)."""
