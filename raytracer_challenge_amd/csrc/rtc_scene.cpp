@@ -245,7 +245,7 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
     stats->rays_container = h.rays_container; stats->accel_nodes = h.accel_nodes; stats->group_tests = h.group_tests; stats->tri_tests = h.tri_tests;
     stats->analytic_tests = h.analytic_tests; stats->nan_ts = h.nan_ts;
     stats->kernel_ms = ms;
-    stats->n_launches = 1;
+    stats->n_launches = wavefront ? 2u * (uint32_t)fuel + 4u : 1u;
   }
   if (std::getenv("RTC_DIAG_DUMP")) {  // RTC_DIAG builds: raw region / utilisation counters for scripts/diag_report.py
     std::fprintf(stderr, "[rtc-diag]");

@@ -24,6 +24,7 @@ class RtcStatsC(C.Structure):
     def as_dict(self):
         d = {n: int(getattr(self, n)) for n, _ in self._fields_[:11]}
         d["kernel_ms"] = float(self.kernel_ms)
+        d["n_launches"] = int(self.n_launches)
         d["unique_rays"] = d["rays_primary"] + d["rays_shadow"] + d["rays_reflect"] + d["rays_refract"]
         return d
 

@@ -30,21 +30,29 @@ static int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double*
   std::vector<int> p(hits ? pm.n : 0), k(hits ? pm.n : 0);
   DStats st;
   std::memset(&st, 0, sizeof(st));
+  unsigned n_launches = 1;
   const char* kv = std::getenv("RTC_KERNEL");
-  if (kv && kv[0] == '4' && pm.n > 0) {  // wavefront path, host-allocated queues
+  if (kv && kv[0] == '4' && pm.n > 0) {  // wavefront path, host-allocated queues (grown on overflow, as the product does)
     const uint64_t n_work = rtc_wavefront_work(cam, pm);
-    const uint64_t cap = std::max<uint64_t>(2 * n_work, 256);
     const int lv = fuel + 1;
-    std::vector<double> dd(cap * (uint64_t)(7 + 7 + 1 + 2 + 13 + 13 + 3 * lv));
-    std::vector<int32_t> ii(cap * (uint64_t)(5 + 2 * lv) + RTC_WF_COUNTS);
-    DWave W{};
-    double* d = dd.data();
-    W.rq[0] = d; d += 7 * cap; W.rq[1] = d; d += 7 * cap; W.h_t = d; d += cap; W.h_n12 = d; d += 2 * cap; W.sr[0] = d; d += 13 * cap; W.sr[1] = d; d += 13 * cap; W.contrib = d;
-    int32_t* q = ii.data();
-    W.h_prim = q; q += cap; W.sr_mat[0] = q; q += cap; W.sr_mat[1] = q; q += cap; W.sr_node[0] = q; q += cap; W.sr_node[1] = q; q += cap; W.child = q; q += 2 * (uint64_t)lv * cap; W.counts = (uint32_t*)q;
-    W.cap = (uint32_t)cap;
-    rtc_launch_wavefront(s->d, cam, pm, fuel, W, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr, 5);
-    if (W.counts[RTC_WF_OVERFLOW]) {  // as the product does: render again with the one-kernel path
+    bool done = false;
+    for (uint64_t mul = 2; mul <= 64 && !done; mul *= 2) {
+      const uint64_t cap = std::max<uint64_t>(mul * n_work, 256);
+      std::vector<double> dd(cap * (uint64_t)(7 + 7 + 1 + 2 + 13 + 13 + 3 * lv));
+      std::vector<int32_t> ii(cap * (uint64_t)(5 + 2 * lv) + RTC_WF_COUNTS);
+      DWave W{};
+      double* d = dd.data();
+      W.rq[0] = d; d += 7 * cap; W.rq[1] = d; d += 7 * cap; W.h_t = d; d += cap; W.h_n12 = d; d += 2 * cap; W.sr[0] = d; d += 13 * cap; W.sr[1] = d; d += 13 * cap; W.contrib = d;
+      int32_t* q = ii.data();
+      W.h_prim = q; q += cap; W.sr_mat[0] = q; q += cap; W.sr_mat[1] = q; q += cap; W.sr_node[0] = q; q += cap; W.sr_node[1] = q; q += cap; W.child = q; q += 2 * (uint64_t)lv * cap;
+      W.counts = (uint32_t*)q;
+      W.cap = (uint32_t)cap;
+      std::memset(&st, 0, sizeof(st));
+      rtc_launch_wavefront(s->d, cam, pm, fuel, W, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr, 5);
+      done = W.counts[RTC_WF_OVERFLOW] == 0;
+      if (done) n_launches = 2u * (unsigned)fuel + 4u;
+    }
+    if (!done) {  // as the product does beyond its memory budget: render again with the one-kernel path
       std::memset(&st, 0, sizeof(st));
       unsigned long long next = 0;
       rtc_launch_trace(s->d, cam, pm, fuel, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr, 0, &next);
@@ -64,7 +72,7 @@ static int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double*
     stats->rays_primary = st.rays_primary; stats->rays_shadow = st.rays_shadow; stats->rays_reflect = st.rays_reflect; stats->rays_refract = st.rays_refract;
     stats->rays_container = st.rays_container; stats->accel_nodes = st.accel_nodes; stats->group_tests = st.group_tests; stats->tri_tests = st.tri_tests;
     stats->analytic_tests = st.analytic_tests; stats->nan_ts = st.nan_ts;
-    stats->n_launches = 1;
+    stats->n_launches = n_launches;
   }
   if (st.guard) return efail(RTC_ERR_DEVICE, "traversal guard tripped (mask " + std::to_string(st.guard) + ")");
   if (st.nan_ts) return efail(RTC_ERR_NAN, "NaN intersection t");

@@ -41,6 +41,30 @@ def test_emulated_other_kernel_versions(emu, orc, version, monkeypatch):
         assert_parity(emu, orc, world, cam, 5, label="kernel v%s %s" % (version, name))
 
 
+def test_wavefront_path_really_runs_in_the_emulator(emu, monkeypatch):
+    """rtc_stats.n_launches tells the paths apart: 1 for the one-kernel path, 2 fuel + 4 for the wavefront path (also after
+    its queues were grown: the glass scene at fuel 8 needs that)."""
+    import ctypes as C
+    from raytracer_challenge_amd.device import RtcCameraC, RtcStatsC
+    monkeypatch.setenv("RTC_KERNEL", "4")
+    lib = emu.lib
+    lib.rtw_world_scene.restype = C.c_void_p
+    lib.rtw_world_scene.argtypes = [C.c_void_p, C.c_int]
+    lib.rtc_render_rows_device.restype = C.c_int
+    lib.rtc_render_rows_device.argtypes = [C.c_void_p, C.POINTER(RtcCameraC), C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(RtcStatsC),
+                                           C.c_int, C.c_int]
+    for (cam, world), fuel in ((scenes.synthetic_analytic(hsize=96, vsize=54), 5), (cases.nested_glass(), 8)):
+        nw = emu.build_world(world)
+        scene = lib.rtw_world_scene(nw.handle, 0)
+        assert scene
+        cc, rc = emu.camera_c(cam), RtcCameraC()
+        assert lib.rtw_make_camera(C.byref(cc), C.byref(rc)) == 0
+        out = np.empty(cam.hsize * cam.vsize * 3)
+        st = RtcStatsC()
+        assert lib.rtc_render_rows_device(scene, C.byref(rc), fuel, 0, 1, cam.vsize, out.ctypes.data, C.byref(st), 1, 1) == 0
+        assert st.as_dict()["n_launches"] == 2 * fuel + 4, st.as_dict()
+
+
 def test_wavefront_and_one_kernel_paths_agree_bitwise(emu, monkeypatch):
     """The wavefront path adds a pixel's contributions in the one-kernel path's order: same bits, whatever the path."""
     for name in ("nested_glass", "synthetic_cones_grouped", "patterns_and_noise", "csg_scene"):
