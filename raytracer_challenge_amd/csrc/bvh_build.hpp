@@ -6,8 +6,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <thread>
 #include <vector>
 
 #include "device_scene.h"
@@ -61,6 +63,28 @@ struct Builder {
   }
   static void store_absent(float* lo, float* hi) {
     for (int a = 0; a < 3; a++) { lo[a] = std::numeric_limits<float>::infinity(); hi[a] = -std::numeric_limits<float>::infinity(); }
+  }
+
+  int par = 1;                                 // threads this subtree may use
+  static constexpr size_t kParMin = 16384;     // smaller ranges are built by the calling thread
+  // Appends a subtree built on private vectors (base 0): node refs shift by the node offset, leaf refs by the item offset.
+  int32_t append(const Builder& sub, int32_t ref) {
+    const int32_t node_off = (int32_t)nodes.size();
+    const uint32_t item_off = base + (uint32_t)order.size();
+    auto fix = [&](int32_t c) -> int32_t {
+      if (c >= 0) return c + node_off;
+      const uint32_t u = (uint32_t)~c;
+      return ~(int32_t)((((u >> 3) + item_off) << 3) | (u & 7u));
+    };
+    const size_t at = nodes.size();
+    nodes.insert(nodes.end(), sub.nodes.begin(), sub.nodes.end());
+    for (size_t i = at; i < nodes.size(); i++) {
+      // an absent child (inverted box) carries a copy of its sibling's ref: shifting it too keeps it harmless
+      nodes[i].c0 = fix(nodes[i].c0);
+      nodes[i].c1 = fix(nodes[i].c1);
+    }
+    order.insert(order.end(), sub.order.begin(), sub.order.end());
+    return fix(ref);
   }
 
   // Builds the subtree over ids[b,e); returns a child ref (>= 0 node, < 0 leaf) and its bounds.
@@ -146,8 +170,27 @@ struct Builder {
     int32_t self = (int32_t)nodes.size();
     nodes.emplace_back();
     Range r0, r1;
-    int32_t c0 = build(ids, b, mid, depth + 1, &r0);
-    int32_t c1 = build(ids, mid, e, depth + 1, &r1);
+    int32_t c0, c1;
+    if (par > 1 && n >= kParMin) {
+      // both halves on private vectors (the left one in another thread; ids[b, mid) and ids[mid, e) are disjoint), then
+      // appended left first: node numbering and leaf order are exactly those of the serial recursion
+      std::vector<DBvhNode> ln, rn;
+      std::vector<uint32_t> lo_, ro_;
+      Builder L{items, ln, lo_, 0}, R{items, rn, ro_, 0};
+      for (Builder* q : {&L, &R}) { q->median_only = median_only; q->kLeaf = kLeaf; for (int a = 0; a < 3; a++) q->center[a] = center[a]; }
+      L.par = par / 2;
+      R.par = par - par / 2;
+      int32_t lc = 0, rc = 0;
+      std::thread th([&]() { lc = L.build(ids, b, mid, depth + 1, &r0); });
+      rc = R.build(ids, mid, e, depth + 1, &r1);
+      th.join();
+      c0 = append(L, lc);
+      c1 = append(R, rc);
+      max_depth = std::max(max_depth, std::max(L.max_depth, R.max_depth));
+    } else {
+      c0 = build(ids, b, mid, depth + 1, &r0);
+      c1 = build(ids, mid, e, depth + 1, &r1);
+    }
     DBvhNode& N = nodes[self];
     store(r0, N.lo0, N.hi0);
     store(r1, N.lo1, N.hi1);
@@ -176,6 +219,12 @@ inline int32_t build(const std::vector<Item>& items, std::vector<DBvhNode>& node
     if (frame) { frame[0] = B.center[0]; frame[1] = B.center[1]; frame[2] = B.center[2]; frame[3] = rad * (1.0 + 1e-6) + 1e-30; }
   }
   B.kLeaf = leaf_max < 1 ? 1 : (leaf_max > 8 ? 8 : leaf_max);
+  {
+    const char* e = std::getenv("RTC_BUILD_THREADS");
+    unsigned hw = std::thread::hardware_concurrency();
+    int t = e ? std::atoi(e) : (int)(hw ? (hw > 8 ? 8 : hw) : 1);  // default: at most 8 (one process per GPU shares the host)
+    B.par = t < 1 ? 1 : (t > 32 ? 32 : t);
+  }
   std::vector<uint32_t> ids(items.size());
   for (uint32_t i = 0; i < ids.size(); i++) ids[i] = i;
   Builder::Range r;

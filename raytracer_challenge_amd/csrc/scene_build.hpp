@@ -2,6 +2,8 @@
 // device_scene.h: the traversal program, the exact group boxes, the accelerator BVHs and the SoA tables.
 // rtc_scene.cpp uploads these arrays verbatim; tests/cpu_emu runs the kernel source on them on the CPU.
 #pragma once
+#include <chrono>
+#include <cstdio>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -205,8 +207,13 @@ struct ProgramBuilder {
       std::vector<DBvhNode> n2;
       bvh_nodes.resize(n0);
       order.resize(o0);
+      auto t0_ = std::chrono::steady_clock::now();
       int32_t root2 = bvh::build(items, n2, order, base, &depth2, attempt == 1, leaf_size(mesh), frame);
+      auto t1_ = std::chrono::steady_clock::now();
       root = bvh::collapse4(n2, root2, bvh_nodes, &depth, &need);
+      if (std::getenv("RTC_TIMING") && items.size() > 100000)
+        std::fprintf(stderr, "[rtc-timing]   SAH build %.3f s, collapse4 %.3f s (%zu items)\n", std::chrono::duration<double>(t1_ - t0_).count(),
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t1_).count(), items.size());
       if (need <= RTC_BVH_STACK - 1) break;
     }
     if (need > RTC_BVH_STACK - 1) { error = "BVH too deep for the traversal stack"; status = RTC_ERR_UNSUPPORTED; }
@@ -480,8 +487,18 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
   int rc = validate(D, err);
   if (rc != RTC_OK) return rc;
   if (D.n_lights > 64) { *err = "more than 64 lights"; return RTC_ERR_INVALID; }
+  const bool timing = std::getenv("RTC_TIMING") != nullptr;
+  auto t_start = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[rtc-timing] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_start).count());
+    t_start = now;
+  };
+  lap("validate");
   ProgramBuilder pb{D};
   if (!pb.emit(0, D.n_nodes) || pb.status != RTC_OK) { *err = pb.error; return pb.status != RTC_OK ? pb.status : RTC_ERR_INVALID; }
+  lap("program + BVH build");
   H->prims.resize(D.n_prims);
   H->all_cast_shadow = 1;
   for (uint32_t i = 0; i < D.n_prims; i++) {
@@ -535,6 +552,7 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
     pb.group_box.insert(pb.group_box.end(), {1, 1, 1, 0, 0, 0});
     pb.group_parent.push_back(-1);
   }
+  lap("array copies");
   H->ops = std::move(pb.ops);
   H->group_box = std::move(pb.group_box);
   H->group_parent = std::move(pb.group_parent);

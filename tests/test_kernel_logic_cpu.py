@@ -41,6 +41,29 @@ def test_emulated_other_kernel_versions(emu, orc, version, monkeypatch):
         assert_parity(emu, orc, world, cam, 5, label="kernel v%s %s" % (version, name))
 
 
+def test_parallel_bvh_build_equals_serial(emu, orc, monkeypatch, tmp_path):
+    """The accelerator build splits large ranges over threads on private vectors and appends them in serial order: same
+    nodes, same leaf order, same pixels as the one-thread build (RTC_BUILD_THREADS)."""
+    import ctypes as C
+    obj = str(tmp_path / "hf.obj")
+    cam, world = scenes.synthetic_mesh(obj, nx=160, nz=160, hsize=64, vsize=36)   # 50 562 triangles: two levels of threads
+    idx = np.arange(0, cam.hsize * cam.vsize, 7, dtype=np.uint64)
+    lib = emu.lib
+    lib.rtw_world_scene.restype = C.c_void_p
+    lib.rtw_world_scene.argtypes = [C.c_void_p, C.c_int]
+    out = {}
+    for threads in ("1", "4"):
+        monkeypatch.setenv("RTC_BUILD_THREADS", threads)
+        nw = emu.build_world(world)
+        scene = lib.rtw_world_scene(nw.handle, 0)
+        info = [C.c_uint32(0) for _ in range(4)]
+        lib.rtc_scene_accel_info(C.c_void_p(scene), *[C.byref(x) for x in info])
+        rgb, hits = emu.render(nw, cam, 3, pixel_indices=idx)
+        out[threads] = ([x.value for x in info], rgb.copy(), hits.copy())
+    assert out["1"][0] == out["4"][0]
+    assert np.array_equal(out["1"][1], out["4"][1]) and np.array_equal(out["1"][2], out["4"][2])
+
+
 def test_wavefront_path_really_runs_in_the_emulator(emu, monkeypatch):
     """rtc_stats.n_launches tells the paths apart: 1 for the one-kernel path, 2 fuel + 4 for the wavefront path (also after
     its queues were grown: the glass scene at fuel 8 needs that)."""
