@@ -234,8 +234,8 @@ def main():
                 dr2 = DeviceRenderer(hip, nw2, c2, device=local_rank)
                 t2 = torch.zeros(c2.vsize * c2.hsize * 3, dtype=torch.float64, device=dev)
                 s2 = dr2.render_rows(args.fuel, 0, 1, c2.vsize, t2, count=True)
-                ms = [dr2.render_rows(args.fuel, 0, 1, c2.vsize, t2)["kernel_ms"] for _ in range(6)]  # the first two measure the paths
-                ms = sum(ms[2:]) / len(ms[2:])
+                ms = [dr2.render_rows(args.fuel, 0, 1, c2.vsize, t2)["kernel_ms"] for _ in range(8)]  # the first four measure the paths
+                ms = sum(ms[4:]) / len(ms[4:])
                 extra[name] = {"workload": d2, "mrays_per_s_kernel": s2["unique_rays"] / ms / 1e3, "kernel_ms": ms, "unique_rays": s2["unique_rays"],
                                "roofline_achieved_GBs": capped_algorithmic_bytes(s2, nw2.primitive_count) / (ms * 1e-3) / 1e9, "accelerator": dr2.info(), "path": dr2.path_info()}
             out["extra"] = extra

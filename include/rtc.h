@@ -198,7 +198,8 @@ void rtc_scene_accel_info(const rtc_scene*, uint32_t* n_ops, uint32_t* n_bvh_nod
  *   1  one kernel: a lane walks its pixel's whole ray tree (rtc_trace_kernel);
  *   4  wavefront: per bounce level a closest-hit + shadow kernel and a shading kernel over ray queues (wf_* kernels).
  * With the environment variable RTC_KERNEL unset the library measures: for one launch shape (camera, rows, fuel) the first
- * two SYNCHRONOUS launches run one path each, every later launch of that shape takes the faster.  Reports the state for
+ * four SYNCHRONOUS launches alternate between the paths (the smaller of a path's two device times counts: a first launch
+ * pays for code loading and scratch), every later launch of that shape takes the faster.  Reports the state for
  * the most recent launch shape: *choice = 0 while undecided, else 1 or 4; the measured device times in ms (< 0 = not yet
  * measured).  Any pointer may be NULL. */
 void rtc_scene_path_info(const rtc_scene*, int32_t* choice, double* one_kernel_ms, double* wavefront_ms);

@@ -59,6 +59,7 @@ struct rtc_scene {
   int kernel_version = 0;  // 0: measured choice between the one-kernel (1) and the wavefront (4) path, per launch signature
   uint64_t tune_sig = 0;
   double tune_ms[2] = {-1.0, -1.0};
+  int tune_n[2] = {0, 0};
   int tune_choice = 0;
   bool last_wavefront = false;
   unsigned long long* d_next = nullptr;  // work counter of the refill variant (RTC_KERNEL=3)
@@ -165,15 +166,16 @@ uint64_t launch_signature(const DCamera& cam, const DPixelMap& pm, int fuel) {
 
 // Which path renders a launch (RTC_KERNEL unset).  The one-kernel path wins on cheap frames (few bounces, ~1 ms), the
 // wavefront path on deep ray trees (config 2: 1.6x); which one depends on scene, camera and fuel, so the choice is
-// measured: for a given launch signature the first two synchronous launches run one path each and every later launch
-// (synchronous or not) takes the faster.  Until then: a guess from the materials and the launch size.  A wavefront launch
+// measured: for a given launch signature the first four synchronous launches alternate between the paths (the smaller of a
+// path's two times counts) and every later launch (synchronous or not) takes the faster.  Until then: a guess from the materials and the launch size.  A wavefront launch
 // whose queues overflowed is rendered again by the one-kernel path and never chosen for that signature, so an
 // unsynchronised wavefront launch only ever repeats a launch that is known to fit.
 int pick_path(rtc_scene* s, uint64_t sig, uint64_t n_work, bool will_sync, bool pixel_list) {
-  if (sig != s->tune_sig) { s->tune_sig = sig; s->tune_ms[0] = s->tune_ms[1] = -1.0; s->tune_choice = 0; }
+  if (sig != s->tune_sig) { s->tune_sig = sig; s->tune_ms[0] = s->tune_ms[1] = -1.0; s->tune_n[0] = s->tune_n[1] = 0; s->tune_choice = 0; }
   if (pixel_list) return 1;  // index lists and explicit rays: small, irregular launches
   if (s->tune_choice) return s->tune_choice;
-  if (will_sync) return s->tune_ms[1] < 0.0 ? 4 : (s->tune_ms[0] < 0.0 ? 1 : 4);
+  // two samples per path, alternating, the smaller one counts: a path's first launch pays for code loading and scratch
+  if (will_sync) return s->tune_n[1] <= s->tune_n[0] ? 4 : 1;
   return 1;
 }
 
@@ -192,7 +194,7 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
   if (wavefront) {
     int rc = ensure_wave(s, rtc_wavefront_work(cam, pm), fuel);
     if (rc == RTC_ERR_UNSUPPORTED && tuned) {  // does not fit the memory budget: this launch shape stays on the one-kernel path
-      s->tune_ms[1] = 1e30; s->tune_choice = 1;
+      s->tune_ms[1] = 1e30; s->tune_n[1] = 2; s->tune_choice = 1;
       return run(s, cam, pm, fuel, d_rgb, want_hits, stats, count, sync, 1);
     }
     if (rc != RTC_OK) return rc;
@@ -224,15 +226,17 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
         s->wave_mul *= 2;
         return run(s, cam, pm, fuel, d_rgb, want_hits, stats, count, true, 4);
       }
-      if (tuned) { s->tune_ms[1] = 1e30; s->tune_choice = 1; }
+      if (tuned) { s->tune_ms[1] = 1e30; s->tune_n[1] = 2; s->tune_choice = 1; }
       return run(s, cam, pm, fuel, d_rgb, want_hits, stats, count, true, 1);
     }
   }
   if (tuned && !count && pm.mode == 2 && !s->tune_choice) {
     float ms = 0.f;
     HIP_OK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
-    s->tune_ms[wavefront ? 1 : 0] = ms;
-    if (s->tune_ms[0] >= 0.0 && s->tune_ms[1] >= 0.0) s->tune_choice = s->tune_ms[1] < s->tune_ms[0] ? 4 : 1;
+    const int k = wavefront ? 1 : 0;
+    s->tune_ms[k] = s->tune_n[k] ? std::min(s->tune_ms[k], (double)ms) : (double)ms;
+    s->tune_n[k]++;
+    if (s->tune_n[0] >= 2 && s->tune_n[1] >= 2) s->tune_choice = s->tune_ms[1] < s->tune_ms[0] ? 4 : 1;
   }
   DStats h;
   HIP_OK(hipMemcpy(&h, s->d_stats, sizeof(h), hipMemcpyDeviceToHost));

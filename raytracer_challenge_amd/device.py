@@ -124,9 +124,9 @@ class DeviceRenderer:
         self.backend.lib.rtc_scene_sync(self.scene)
 
     def tune(self, fuel: int, row_first: int, row_step: int, n_rows: int, out_tensor) -> dict:
-        """Lets the library measure both device paths for this launch shape (two synchronous renders into out_tensor) so
-        that later launches, including unsynchronised ones, take the faster; returns path_info()."""
-        for _ in range(2):
+        """Lets the library measure both device paths for this launch shape (four synchronous renders into out_tensor, two
+        per path) so that later launches, including unsynchronised ones, take the faster; returns path_info()."""
+        for _ in range(4):
             self.render_rows(fuel, row_first, row_step, n_rows, out_tensor, count=False, sync=True, want_stats=False)
         return self.path_info()
 

@@ -116,7 +116,7 @@ def test_hip_wavefront_queue_growth_and_fallback(hip, orc, monkeypatch):
 
 
 def test_hip_measured_path_choice(hip):
-    """DeviceRenderer.tune(): two synchronous launches measure both paths, later launches (also unsynchronised ones) take
+    """DeviceRenderer.tune(): four synchronous launches measure both paths twice, later launches (also unsynchronised ones) take
     the faster; whatever is chosen, the pixels are those of a plain synchronous render."""
     import torch
     from raytracer_challenge_amd.device import DeviceRenderer
