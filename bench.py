@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="config2")
     ap.add_argument("--fuel", type=int, default=None, help="recursion depth (default: 5; 8 for config4/config5)")
+    ap.add_argument("--inflight", type=int, default=0, help="frames in flight per GPU, each on its own scene copy and HIP stream "
+                    "(default: 1 on one GPU, 3 on several, where the per-rank frames are small and latency-bound)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extra-workloads", default="config3", help="comma list measured (untimed region) and reported under 'extra' at N=1")
     args = ap.parse_args()
@@ -149,28 +151,33 @@ def main():
 
     hip = rt.hip_backend()  # raises if the HIP library is missing
     cam, world, desc = make_workload(args.workload)
-    nw = hip.build_world(world)
-    dr = DeviceRenderer(hip, nw, cam, device=local_rank)
+    # F frames in flight: F copies of the uploaded scene, each with its own HIP stream (and wavefront buffers), frames dealt
+    # round-robin.  A frame's per-level kernels are latency-bound at the small deep levels (and at the small per-rank frames of
+    # an N-GPU run); the next frames' kernels fill the chip meanwhile.
+    F = args.inflight if args.inflight > 0 else (1 if world_size == 1 else 3)
+    nws = [hip.build_world(world) for _ in range(F)]
+    drs = [DeviceRenderer(hip, w, cam, device=local_rank) for w in nws]
+    nw, dr = nws[0], drs[0]
     H, V = cam.hsize, cam.vsize
     from raytracer_challenge_amd.parallel import FrameGatherer
-    fg = FrameGatherer(H, V, rank, world_size, dev, dist)
+    fg = FrameGatherer(H, V, rank, world_size, dev, dist, n_buffers=F)
 
     def finish(i):
-        """Frame i: wait for its render (marker i % 2), then gather its tiles to rank 0 (RCCL) and de-interleave."""
-        dr.wait(i % 2)
+        """Frame i: wait for its render (marker 0 of its renderer), then gather its tiles to rank 0 (RCCL) and de-interleave."""
+        drs[i % F].wait(0)
         if world_size > 1:
-            fg.gather(i % 2)
-            torch.cuda.current_stream().synchronize()  # tiles[i % 2] is free again once the gather has consumed it
+            fg.gather(i % F)
+            torch.cuda.current_stream().synchronize()  # tiles[i % F] is free again once the gather has consumed it
 
     def run_frames(k):
-        """k full frames, software-pipelined: the render of frame i overlaps the gather of frame i-1."""
+        """k full frames, software-pipelined: up to F renders in flight; the gather of frame i - F runs behind them."""
         for i in range(k):
-            dr.render_rows_async(args.fuel, rank, world_size, fg.n_rows, fg.tiles[i % 2])
-            dr.record(i % 2)
-            if i > 0:
-                finish(i - 1)
-        if k > 0:
-            finish(k - 1)
+            if i >= F:
+                finish(i - F)
+            drs[i % F].render_rows_async(args.fuel, rank, world_size, fg.n_rows, fg.tiles[i % F])
+            drs[i % F].record(0)
+        for i in range(max(0, k - F), k):
+            finish(i)
 
     # untimed: counting variant -> unique rays + algorithmic bytes of this rank's launch
     cst = dr.render_rows(args.fuel, rank, world_size, fg.n_rows, fg.tiles[0], count=True, sync=True)
@@ -179,31 +186,47 @@ def main():
         dist.all_reduce(rays_local)
     rays_total = float(rays_local.item())
 
-    path = dr.tune(args.fuel, rank, world_size, fg.n_rows, fg.tiles[0])  # untimed: both device paths measured once, faster one kept
+    # untimed: both device paths measured twice per renderer, the faster one kept
+    paths = [d.tune(args.fuel, rank, world_size, fg.n_rows, fg.tiles[j]) for j, d in enumerate(drs)]
+    path = paths[0]
     run_frames(args.warmup)
-    dr.check()
+    for d in drs:
+        d.check()
     if world_size > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    dr.sync()
-    dr.record(2)                      # stream markers 2..3 bracket the timed region's launches on the kernel's own stream
+    for d in drs:
+        d.sync()
+        d.record(2)                   # stream markers 2..3 bracket the timed region's launches on each renderer's own stream
     t0 = time.perf_counter()
     run_frames(args.steps)
-    dr.record(3)
-    dr.sync()
+    for d in drs:
+        d.record(3)
+    for d in drs:
+        d.sync()
     torch.cuda.synchronize()
     if world_size > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    dr.check()                        # NaN / guard flags of the timed launches
-    kernel_ms = [dr.elapsed_ms(2, 3) / max(1, args.steps)]
+    for d in drs:
+        d.check()                     # NaN / guard / overflow flags of the timed launches
+    # device time per frame: throughput view (the timed region on the busiest stream / all frames) and latency view (a
+    # stream's region / the frames it rendered: what rocprofv3's per-kernel durations add up to)
+    used = [j for j in range(F) if j < args.steps]
+    region_ms = [drs[j].elapsed_ms(2, 3) for j in used]
+    frames_on = [len(range(j, args.steps, F)) for j in used]
+    kernel_ms = [max(region_ms) / max(1, args.steps)]
+    latency_ms = sum(r / f for r, f in zip(region_ms, frames_on)) / len(used)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world_size > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
     if rank == 0:
-        avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+        # roofline per launch: a frame's own device time (latency view, comparable with rocprofv3's kernel durations); frames
+        # in flight overlap, so the chip-wide rate is the throughput view
+        throughput_ms = sum(kernel_ms) / len(kernel_ms)
+        avg_kernel_ms = latency_ms
         alg_bytes = capped_algorithmic_bytes(cst, nw.primitive_count)
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
         out = {
@@ -221,7 +244,8 @@ def main():
                          "traffic": pmc_traffic(args.workload, path["path"])[0] if world_size == 1 else None, "traffic_source": pmc_traffic(args.workload, path["path"])[1],
                          "kernel": ("wavefront frame = wf_ts x%d + wf_shade x%d + wf_gather (dominant: wf_ts)" % (args.fuel + 2, args.fuel + 1))
                                    if path["path"] == "wavefront" else "rtc_trace_kernel",
-                         "kernel_ms_avg": avg_kernel_ms, "path": path, "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel_ms_avg": avg_kernel_ms, "frames_in_flight": F, "device_ms_per_frame_all_streams": throughput_ms,
+                         "achieved_all_streams": alg_bytes / (throughput_ms * 1e-3) / 1e9, "path": path, "algorithmic_bytes_per_launch": alg_bytes,
                          "counters_rank0": {k: cst[k] for k in ("pixels", "unique_rays", "accel_nodes", "group_tests", "tri_tests", "analytic_tests", "rays_container")},
                          "note": "scene (%d B) is L2/Infinity-Cache resident; real HBM traffic ~ framebuffer only (SURVEY.md §8d)" % dr.info()["scene_device_bytes"]},
             "accelerator": dr.info(),

@@ -23,13 +23,13 @@ class FrameGatherer:
     """Owns the gather buffers of one frame size.  `tile` is each rank's dense buffer of its own rows (float64,
     max_rows*hsize*3, padded when vsize % world_size != 0)."""
 
-    def __init__(self, hsize: int, vsize: int, rank: int, world_size: int, device, dist=None):
+    def __init__(self, hsize: int, vsize: int, rank: int, world_size: int, device, dist=None, n_buffers: int = 2):
         import torch
         self.hsize, self.vsize, self.rank, self.world_size, self.dist = hsize, vsize, rank, world_size, dist
         self.n_rows = len(rows_of(rank, world_size, vsize))
         self.max_rows = max_rows(world_size, vsize)
-        # two tiles: frame i renders into tiles[i % 2] while frame i-1 is gathered from the other one
-        self.tiles = [torch.zeros(self.max_rows * hsize * 3, dtype=torch.float64, device=device) for _ in range(2)]
+        # n_buffers tiles: frame i renders into tiles[i % n_buffers] while earlier frames are still in flight / being gathered
+        self.tiles = [torch.zeros(self.max_rows * hsize * 3, dtype=torch.float64, device=device) for _ in range(max(1, n_buffers))]
         self.tile = self.tiles[0]
         self.gathered: Optional[List] = None
         self.image = None
