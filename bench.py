@@ -140,14 +140,23 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world_size
     dist = None
+    # RTC_BENCH_REHEARSE=1: rehearsal of the multi-rank code path on a one-GPU box (every rank on cuda:0, gloo gather through
+    # host memory).  Its numbers mean nothing; the driver's N-GPU runs never set it.
+    rehearse = world_size > 1 and os.environ.get("RTC_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     if world_size > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    gather_dev = torch.device("cpu") if rehearse else dev
 
     hip = rt.hip_backend()  # raises if the HIP library is missing
     cam, world, desc = make_workload(args.workload)
@@ -160,7 +169,7 @@ def main():
     nw, dr = nws[0], drs[0]
     H, V = cam.hsize, cam.vsize
     from raytracer_challenge_amd.parallel import FrameGatherer
-    fg = FrameGatherer(H, V, rank, world_size, dev, dist, n_buffers=F)
+    fg = FrameGatherer(H, V, rank, world_size, gather_dev, dist, n_buffers=F, tile_device=dev)
 
     def finish(i):
         """Frame i: wait for its render (marker 0 of its renderer), then gather its tiles to rank 0 (RCCL) and de-interleave."""
@@ -181,7 +190,7 @@ def main():
 
     # untimed: counting variant -> unique rays + algorithmic bytes of this rank's launch
     cst = dr.render_rows(args.fuel, rank, world_size, fg.n_rows, fg.tiles[0], count=True, sync=True)
-    rays_local = torch.tensor([float(cst["unique_rays"])], dtype=torch.float64, device=dev)
+    rays_local = torch.tensor([float(cst["unique_rays"])], dtype=torch.float64, device=gather_dev)
     if world_size > 1:
         dist.all_reduce(rays_local)
     rays_total = float(rays_local.item())
@@ -217,7 +226,7 @@ def main():
     frames_on = [len(range(j, args.steps, F)) for j in used]
     kernel_ms = [max(region_ms) / max(1, args.steps)]
     latency_ms = sum(r / f for r, f in zip(region_ms, frames_on)) / len(used)
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
     if world_size > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())

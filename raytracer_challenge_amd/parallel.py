@@ -23,13 +23,16 @@ class FrameGatherer:
     """Owns the gather buffers of one frame size.  `tile` is each rank's dense buffer of its own rows (float64,
     max_rows*hsize*3, padded when vsize % world_size != 0)."""
 
-    def __init__(self, hsize: int, vsize: int, rank: int, world_size: int, device, dist=None, n_buffers: int = 2):
+    def __init__(self, hsize: int, vsize: int, rank: int, world_size: int, device, dist=None, n_buffers: int = 2, tile_device=None):
         import torch
         self.hsize, self.vsize, self.rank, self.world_size, self.dist = hsize, vsize, rank, world_size, dist
         self.n_rows = len(rows_of(rank, world_size, vsize))
         self.max_rows = max_rows(world_size, vsize)
         # n_buffers tiles: frame i renders into tiles[i % n_buffers] while earlier frames are still in flight / being gathered
-        self.tiles = [torch.zeros(self.max_rows * hsize * 3, dtype=torch.float64, device=device) for _ in range(max(1, n_buffers))]
+        # tile_device != device only in rehearsals of the multi-rank path on one GPU (tiles in HBM, gloo gather through host memory)
+        self.gather_device = device
+        self.tiles = [torch.zeros(self.max_rows * hsize * 3, dtype=torch.float64, device=tile_device if tile_device is not None else device)
+                      for _ in range(max(1, n_buffers))]
         self.tile = self.tiles[0]
         self.gathered: Optional[List] = None
         self.image = None
@@ -48,6 +51,10 @@ class FrameGatherer:
         """All ranks call this after tiles[which] is complete.  Rank 0 returns the assembled (vsize, hsize, 3) image, others None."""
         H, V, N = self.hsize, self.vsize, self.world_size
         tile = self.tiles[which]
+        if tile.device != self.image.device if self.image is not None else False:
+            tile = tile.to(self.image.device)
+        elif self.image is None and str(tile.device) != str(self.gather_device):
+            tile = tile.to(self.gather_device)
         if N == 1:
             self.image.view(-1)[:] = tile[: V * H * 3]
             return self.image
