@@ -33,6 +33,14 @@ struct DOp {  // 32 bytes
   int32_t pad[3];
 };
 
+#define RTC_KOPS 12
+#define RTC_KPLANES 6
+struct DPlaneK {  // 48 bytes: what Plane::intersect reads (row 1 of transform_inv) + the primitive's index
+  double row[4];
+  int32_t prim;
+  int32_t pad[3];
+};
+
 // 64-byte BVH2 node: both children's boxes (f32, rounded outward) + child refs.
 // ref >= 0: inner node index.  ref < 0: leaf, items [first, first+count) with first = (~ref) >> 3,
 // count = ((~ref) & 7) + 1.  An absent child has an inverted box (lo = +inf, hi = -inf).
@@ -131,6 +139,13 @@ struct DScene {
   int32_t has_mesh;          // 1: the program contains an OP_MESH
   int32_t has_csg;           // 1: the program contains an OP_CSG
   int32_t has_groups;        // 0: no gates; 1: only OP_MESH / OP_CSG ops are gated; 2: individual primitives are gated
+  // Kernel-argument copy of a short traversal program (kernargs are read with scalar loads: the op fetch and the plane
+  // records stop being per-lane vector loads on every ray's dependency chain).  Used when n_kops > 0: the whole program
+  // has <= RTC_KOPS ops, no OP_GROUP / OP_CSG, no per-primitive gates (so every lane runs the same op sequence); an
+  // OP_PRIM whose primitive is a plane carries its slot in kplanes in `c` (else -1).
+  int32_t n_kops, n_kplanes;
+  DOp kops[RTC_KOPS];
+  DPlaneK kplanes[RTC_KPLANES];
   // array lengths, for the traversal guards (a bad index retires the lane and raises DStats.guard instead of faulting)
   int32_t bvh_stack;  // entries each lane's traversal stack needs for this scene's trees (LDS is sized from it at launch)
   int32_t n_bvh, n_items, n_mtri, n_quirk, n_qitem, n_qcell, n_groups, n_qgrids;

@@ -590,6 +590,43 @@ __device__ __noinline__ int csg_eval(const DScene& S, int pc, const Ray& r, Trav
 // CSGK: the kernel instantiation for scenes that contain CSG groups; all others never see the (register-hungry) call.
 template <int FEAT>
 __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T, Counters& C, int* __restrict__ stack, int stride) {
+  if (FEAT <= 1 && S.n_kops > 0) {
+    // short jump-free program from the kernel arguments: pc is wave-uniform, the op and the plane records are scalar loads
+    for (int pc = 0; pc < S.n_kops; pc++) {
+      DIAG_LOOP(2);
+      const DOp op = S.kops[pc];
+      if (op.op == OP_PRIM) {
+        if (op.c >= 0) {
+          // Plane (src/shape.rs:621-633): the same row-1 evaluation as visit_prim's plane case, operands from kernargs
+          const DPlaneK P = S.kplanes[op.c];
+          C.analytic_tests++;
+          double oy = P.row[0] * r.ox + P.row[1] * r.oy + P.row[2] * r.oz + P.row[3] * 1.0;
+          double dy = P.row[0] * r.dx + P.row[1] * r.dy + P.row[2] * r.dz + P.row[3] * 0.0;
+          if (!(fabs(dy - 0.0) < EPS)) {
+            double t = -oy / dy;
+            accept(T, C, P.prim, 1, &t);
+          }
+        } else {
+          visit_prim<FEAT>(S, op.a, r, T, C, 0);
+        }
+      } else if (op.op == OP_QUIRK) {
+        for (int i = op.a; i < op.a + op.b; i++) visit_prim<FEAT>(S, S.quirk_prim[i], r, T, C, 2);
+      } else if (op.op == OP_QGRID) {
+        DIAG_SPAN_BEGIN();
+        quirk_grid_scan<FEAT>(S, S.qgrids[op.a], r, T, C);
+        DIAG_SPAN_END(4);
+      } else if (op.op == OP_MESH) {
+        if (FEAT == 0 || op.g < 0 || groups_pass<false>(S, op.g, r, T, C)) {
+          Ray o = to_object(S.xf_inv + 12 * op.b, r);
+          bvh_walk<true, FEAT>(S, op.a, op.c, r, o, T, C, stack, stride);
+        }
+      } else {
+        bvh_walk<false, FEAT>(S, op.a, op.c, r, r, T, C, stack, stride);
+      }
+      if (T.mode == MODE_SHADOW_ANY && T.shadowed) return;
+    }
+    return;
+  }
   int pc = 0;
   const int n = S.n_ops;
   while (pc < n) {

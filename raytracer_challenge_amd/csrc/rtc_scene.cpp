@@ -323,6 +323,9 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     d.has_mesh = hv.has_mesh;
     d.has_csg = hv.has_csg;
     d.has_groups = hv.has_groups;
+    d.n_kops = hv.n_kops; d.n_kplanes = hv.n_kplanes;
+    std::memcpy(d.kops, hv.kops, sizeof(d.kops));
+    std::memcpy(d.kplanes, hv.kplanes, sizeof(d.kplanes));
     d.n_bvh = hv.n_bvh; d.n_items = hv.n_items; d.n_mtri = hv.n_mtri; d.n_quirk = hv.n_quirk;
     d.n_qitem = hv.n_qitem; d.n_qcell = hv.n_qcell; d.n_groups = hv.n_groups; d.n_qgrids = hv.n_qgrids;
   }

@@ -459,6 +459,26 @@ struct HostArrays {
   std::vector<double> lights;
   int32_t n_lights = 0, all_cast_shadow = 1, bvh_depth = 0, bvh_stack = 8;
 
+  // DScene.kops / kplanes (device_scene.h): a short, jump-free program travels in the kernel arguments.
+  void fill_kernarg_program(DScene& d) const {
+    d.n_kops = 0; d.n_kplanes = 0;
+    if (std::getenv("RTC_NO_KOPS")) return;
+    if (ops.size() > RTC_KOPS || d.has_csg || d.has_groups == 2) return;
+    for (const DOp& o : ops) if (o.op == OP_GROUP || o.op == OP_CSG || o.op == OP_CSG_END) return;
+    for (size_t i = 0; i < ops.size(); i++) {
+      DOp o = ops[i];
+      o.c = (o.op == OP_PRIM) ? -1 : o.c;
+      if (o.op == OP_PRIM && prims[(size_t)o.a].geom == RTC_PLANE && d.n_kplanes < RTC_KPLANES) {
+        DPlaneK& k = d.kplanes[d.n_kplanes];
+        std::memcpy(k.row, &xf_inv[(size_t)prims[(size_t)o.a].xform * 12 + 4], 4 * sizeof(double));
+        k.prim = o.a;
+        o.c = d.n_kplanes++;
+      }
+      d.kops[i] = o;
+    }
+    d.n_kops = (int32_t)ops.size();
+  }
+
   DScene view() const {
     DScene d{};
     d.ops = ops.data(); d.group_box = group_box.data(); d.group_parent = group_parent.data(); d.bvh = bvh.data(); d.mtri = mtri.data(); d.mtri_prim = mtri_prim.data();
@@ -478,6 +498,7 @@ struct HostArrays {
     for (int32_t pi : items) if (prims[pi].gcond >= 0) d.has_groups = 2;
     for (int32_t pi : bvh_prims) if (prims[pi].gcond >= 0) d.has_groups = 2;
     for (const DOp& o : ops) { if (o.op == OP_MESH) d.has_mesh = 1; if (o.op == OP_CSG) d.has_csg = 1; }
+    fill_kernarg_program(d);
     return d;
   }
 };
