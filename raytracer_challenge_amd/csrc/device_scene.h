@@ -69,6 +69,14 @@ struct DQuirkGrid {
 };
 #define RTC_QGRID_MIN_LEN 0.05
 
+// Kernel-argument copy of what every ray reads first of a BVH: its frame, (meshes) the world -> object matrix, the root node.
+#define RTC_KAUX 3
+struct DKAux {
+  double frame[4];
+  double xf[12];
+  DBvhNode4 root;
+};
+
 // One CSG group: kind (RTC_NODE_UNION / _INTERSECTION / _DIFFERENCE) and the primitive range of children[0] (DFS order makes
 // "children[0].includes(shape)" a range test on the sequence number).
 struct DCsg {
@@ -144,8 +152,10 @@ struct DScene {
   // has <= RTC_KOPS ops, no OP_GROUP / OP_CSG, no per-primitive gates (so every lane runs the same op sequence); an
   // OP_PRIM whose primitive is a plane carries its slot in kplanes in `c` (else -1).
   int32_t n_kops, n_kplanes;
-  DOp kops[RTC_KOPS];
+  DOp kops[RTC_KOPS];        // pad[0]: OP_BVH / OP_MESH -> slot in kaux, OP_QGRID -> 0 if kqgrid is its grid; -1 = read from memory
   DPlaneK kplanes[RTC_KPLANES];
+  DKAux kaux[RTC_KAUX];
+  DQuirkGrid kqgrid;
   // array lengths, for the traversal guards (a bad index retires the lane and raises DStats.guard instead of faulting)
   int32_t bvh_stack;  // entries each lane's traversal stack needs for this scene's trees (LDS is sized from it at launch)
   int32_t n_bvh, n_items, n_mtri, n_quirk, n_qitem, n_qcell, n_groups, n_qgrids;

@@ -444,13 +444,59 @@ __device__ __forceinline__ bool slab32c(float lx, float ly, float lz, float hx, 
   return fmaxf(tn, tlo) <= fminf(tf, thi) && lx <= hx;
 }
 
+// One inner-node step of the walk: the node's four child boxes against the ray; hits ordered nearest first, the nearest
+// becomes `cur`, the others are stacked; no hit pops (or ends the walk: cur = END).
+#define RTC_WALK_END ((int)0x80000000)
+__device__ __forceinline__ void node_step(const float4 lox, const float4 loy, const float4 loz, const float4 hix, const float4 hiy, const float4 hiz, const int4 cc,
+                                          const Frame32& F, float lo, float hi, int& cur, int& sp, int* __restrict__ stack, int stride) {
+  const float FINF = __builtin_inff();
+  float t0, t1, t2, t3;
+  bool h0 = slab32c(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, F, lo, hi, t0);
+  bool h1 = slab32c(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, F, lo, hi, t1);
+  bool h2 = slab32c(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, F, lo, hi, t2);
+  bool h3 = slab32c(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, F, lo, hi, t3);
+  const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+  if (nh == 0) {
+    if (sp == 0) cur = RTC_WALK_END;
+    else { sp--; cur = stack[sp * stride]; }
+    return;
+  }
+  // order the (entry distance, child) pairs: a hit's key is finite (min with FLT_MAX also replaces a NaN), a miss's
+  // is +inf, so after the network the first nh pairs are exactly the hits, nearest first
+  const float FMAXV = 3.4028234663852886e38f;
+  t0 = h0 ? fminf(t0, FMAXV) : FINF; t1 = h1 ? fminf(t1, FMAXV) : FINF; t2 = h2 ? fminf(t2, FMAXV) : FINF; t3 = h3 ? fminf(t3, FMAXV) : FINF;
+  int c0 = cc.x, c1 = cc.y, c2 = cc.z, c3 = cc.w;
+#define RTC_CSWAP(ta, ca, tb, cb) { const bool s_ = tb < ta; const float tt_ = s_ ? tb : ta; const int ct_ = s_ ? cb : ca; tb = s_ ? ta : tb; cb = s_ ? ca : cb; ta = tt_; ca = ct_; }
+  RTC_CSWAP(t0, c0, t1, c1) RTC_CSWAP(t2, c2, t3, c3) RTC_CSWAP(t0, c0, t2, c2) RTC_CSWAP(t1, c1, t3, c3) RTC_CSWAP(t1, c1, t2, c2)
+#undef RTC_CSWAP
+  if (nh > 3) { stack[sp * stride] = c3; sp++; }
+  if (nh > 2) { stack[sp * stride] = c2; sp++; }
+  if (nh > 1) { stack[sp * stride] = c1; sp++; }
+  cur = c0;
+}
+
+// kroot / kframe: the root node and the frame of this BVH from the kernel arguments (DScene.kaux; scalar loads) or nullptr.
 template <bool MESH, int FEAT>
-__device__ __forceinline__ void bvh_walk(const DScene& S, int root, int frame, const Ray& world, const Ray& o, Trav& T, Counters& C, int* __restrict__ stack, int stride) {
+__device__ __forceinline__ void bvh_walk(const DScene& S, int root, int frame, const Ray& world, const Ray& o, Trav& T, Counters& C, int* __restrict__ stack, int stride,
+                                         const DBvhNode4* kroot = nullptr, const double* kframe = nullptr) {
   Frame32 F;
-  make_frame(S.bvh_frame + 4 * frame, o, F);
-  const int END = (int)0x80000000;
+  make_frame(kframe ? kframe : S.bvh_frame + 4 * frame, o, F);
+  const int END = RTC_WALK_END;
   int sp = 0;
   int cur = root;
+#ifdef RTC_NO_KROOT
+  kroot = nullptr;
+#endif
+  if (kroot) {  // every lane starts at the root: its boxes come from the kernel arguments
+    C.accel_nodes++;
+    float lo, hi;
+    t_interval32(T, lo, hi);
+    const float4 lox = {kroot->lox[0], kroot->lox[1], kroot->lox[2], kroot->lox[3]}, loy = {kroot->loy[0], kroot->loy[1], kroot->loy[2], kroot->loy[3]};
+    const float4 loz = {kroot->loz[0], kroot->loz[1], kroot->loz[2], kroot->loz[3]}, hix = {kroot->hix[0], kroot->hix[1], kroot->hix[2], kroot->hix[3]};
+    const float4 hiy = {kroot->hiy[0], kroot->hiy[1], kroot->hiy[2], kroot->hiy[3]}, hiz = {kroot->hiz[0], kroot->hiz[1], kroot->hiz[2], kroot->hiz[3]};
+    const int4 cc = {kroot->c[0], kroot->c[1], kroot->c[2], kroot->c[3]};
+    node_step(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride);
+  }
   for (;;) {
     DIAG_LOOP(0);
     // "while-while": descend through inner nodes until this lane holds a leaf (or has drained its stack); lanes that
@@ -464,30 +510,7 @@ __device__ __forceinline__ void bvh_walk(const DScene& S, int root, int frame, c
       // the node's seven 16-byte rows: one line, all loads in flight together
       const float4 lox = ld4(N->lox), loy = ld4(N->loy), loz = ld4(N->loz), hix = ld4(N->hix), hiy = ld4(N->hiy), hiz = ld4(N->hiz);
       const int4 cc = ld4(N->c);
-      const float FINF = __builtin_inff();
-      float t0, t1, t2, t3;
-      bool h0 = slab32c(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, F, lo, hi, t0);
-      bool h1 = slab32c(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, F, lo, hi, t1);
-      bool h2 = slab32c(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, F, lo, hi, t2);
-      bool h3 = slab32c(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, F, lo, hi, t3);
-      const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
-      if (nh == 0) {
-        if (sp == 0) cur = END;
-        else { sp--; cur = stack[sp * stride]; }
-        continue;
-      }
-      // order the (entry distance, child) pairs: a hit's key is finite (min with FLT_MAX also replaces a NaN), a miss's
-      // is +inf, so after the network the first nh pairs are exactly the hits, nearest first
-      const float FMAXV = 3.4028234663852886e38f;
-      t0 = h0 ? fminf(t0, FMAXV) : FINF; t1 = h1 ? fminf(t1, FMAXV) : FINF; t2 = h2 ? fminf(t2, FMAXV) : FINF; t3 = h3 ? fminf(t3, FMAXV) : FINF;
-      int c0 = cc.x, c1 = cc.y, c2 = cc.z, c3 = cc.w;
-#define RTC_CSWAP(ta, ca, tb, cb) { const bool s_ = tb < ta; const float tt_ = s_ ? tb : ta; const int ct_ = s_ ? cb : ca; tb = s_ ? ta : tb; cb = s_ ? ca : cb; ta = tt_; ca = ct_; }
-      RTC_CSWAP(t0, c0, t1, c1) RTC_CSWAP(t2, c2, t3, c3) RTC_CSWAP(t0, c0, t2, c2) RTC_CSWAP(t1, c1, t3, c3) RTC_CSWAP(t1, c1, t2, c2)
-#undef RTC_CSWAP
-      if (nh > 3) { stack[sp * stride] = c3; sp++; }
-      if (nh > 2) { stack[sp * stride] = c2; sp++; }
-      if (nh > 1) { stack[sp * stride] = c1; sp++; }
-      cur = c0;
+      node_step(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride);
     }
     if (cur == END) return;
     {
@@ -613,15 +636,22 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
         for (int i = op.a; i < op.a + op.b; i++) visit_prim<FEAT>(S, S.quirk_prim[i], r, T, C, 2);
       } else if (op.op == OP_QGRID) {
         DIAG_SPAN_BEGIN();
-        quirk_grid_scan<FEAT>(S, S.qgrids[op.a], r, T, C);
+        quirk_grid_scan<FEAT>(S, op.pad[0] >= 0 ? S.kqgrid : S.qgrids[op.a], r, T, C);
         DIAG_SPAN_END(4);
       } else if (op.op == OP_MESH) {
         if (FEAT == 0 || op.g < 0 || groups_pass<false>(S, op.g, r, T, C)) {
-          Ray o = to_object(S.xf_inv + 12 * op.b, r);
-          bvh_walk<true, FEAT>(S, op.a, op.c, r, o, T, C, stack, stride);
+          if (op.pad[0] >= 0) {
+            const DKAux& A = S.kaux[op.pad[0]];
+            Ray o = to_object(A.xf, r);
+            bvh_walk<true, FEAT>(S, op.a, op.c, r, o, T, C, stack, stride, &A.root, A.frame);
+          } else {
+            Ray o = to_object(S.xf_inv + 12 * op.b, r);
+            bvh_walk<true, FEAT>(S, op.a, op.c, r, o, T, C, stack, stride);
+          }
         }
       } else {
-        bvh_walk<false, FEAT>(S, op.a, op.c, r, r, T, C, stack, stride);
+        if (op.pad[0] >= 0) bvh_walk<false, FEAT>(S, op.a, op.c, r, r, T, C, stack, stride, &S.kaux[op.pad[0]].root, S.kaux[op.pad[0]].frame);
+        else bvh_walk<false, FEAT>(S, op.a, op.c, r, r, T, C, stack, stride);
       }
       if (T.mode == MODE_SHADOW_ANY && T.shadowed) return;
     }

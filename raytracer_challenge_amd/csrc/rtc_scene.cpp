@@ -326,6 +326,8 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     d.n_kops = hv.n_kops; d.n_kplanes = hv.n_kplanes;
     std::memcpy(d.kops, hv.kops, sizeof(d.kops));
     std::memcpy(d.kplanes, hv.kplanes, sizeof(d.kplanes));
+    std::memcpy(d.kaux, hv.kaux, sizeof(d.kaux));
+    d.kqgrid = hv.kqgrid;
     d.n_bvh = hv.n_bvh; d.n_items = hv.n_items; d.n_mtri = hv.n_mtri; d.n_quirk = hv.n_quirk;
     d.n_qitem = hv.n_qitem; d.n_qcell = hv.n_qcell; d.n_groups = hv.n_groups; d.n_qgrids = hv.n_qgrids;
   }

@@ -465,9 +465,21 @@ struct HostArrays {
     if (std::getenv("RTC_NO_KOPS")) return;
     if (ops.size() > RTC_KOPS || d.has_csg || d.has_groups == 2) return;
     for (const DOp& o : ops) if (o.op == OP_GROUP || o.op == OP_CSG || o.op == OP_CSG_END) return;
+    int n_aux = 0;
+    bool have_qgrid = false;
     for (size_t i = 0; i < ops.size(); i++) {
       DOp o = ops[i];
       o.c = (o.op == OP_PRIM) ? -1 : o.c;
+      o.pad[0] = -1;
+      if ((o.op == OP_BVH || o.op == OP_MESH) && n_aux < RTC_KAUX && o.a >= 0) {
+        DKAux& A = d.kaux[n_aux];
+        std::memcpy(A.frame, &bvh_frame[(size_t)o.c * 4], 4 * sizeof(double));
+        if (o.op == OP_MESH) std::memcpy(A.xf, &xf_inv[(size_t)o.b * 12], 12 * sizeof(double));
+        else std::memset(A.xf, 0, sizeof(A.xf));
+        A.root = bvh[(size_t)o.a];
+        o.pad[0] = n_aux++;
+      }
+      if (o.op == OP_QGRID && !have_qgrid) { d.kqgrid = qgrids[(size_t)o.a]; have_qgrid = true; o.pad[0] = 0; }
       if (o.op == OP_PRIM && prims[(size_t)o.a].geom == RTC_PLANE && d.n_kplanes < RTC_KPLANES) {
         DPlaneK& k = d.kplanes[d.n_kplanes];
         std::memcpy(k.row, &xf_inv[(size_t)prims[(size_t)o.a].xform * 12 + 4], 4 * sizeof(double));
