@@ -1375,7 +1375,9 @@ __device__ __forceinline__ void wf_trace_ray(const DScene& S, const DCamera& cam
 
 template <bool COUNT>
 __global__ void __launch_bounds__(RTC_WF_SHADE_BLOCK) wf_shade(DScene S, DCamera cam, DPixelMap pm, DWave W, int level, unsigned n0, int fuel0, DStats* __restrict__ stats) {
-  __shared__ unsigned s_rec[16], s_child[16];  // per wave: its count, then its base index in the queue
+  __shared__ unsigned s_rec2[2][16], s_child2[2][16];  // per wave: its count, then its base index in the queue (double-buffered
+                                                       // by iteration parity: no barrier needed before the next iteration writes)
+  unsigned parity = 0;
   const WorkMap wm = make_workmap(pm, cam);
   const unsigned count = wf_count(W, level, n0);
   const size_t cap = W.cap;
@@ -1451,6 +1453,9 @@ __global__ void __launch_bounds__(RTC_WF_SHADE_BLOCK) wf_shade(DScene S, DCamera
     // atomics per block and iteration
     const unsigned long long lt = (1ull << lane) - 1ull;
     const unsigned long long m_rec = __ballot(hit ? 1 : 0), m_refl = __ballot(do_refl ? 1 : 0), m_refr = __ballot(do_refr ? 1 : 0);
+    unsigned* s_rec = s_rec2[parity];
+    unsigned* s_child = s_child2[parity];
+    parity ^= 1u;
     if (lane == 0) { s_rec[wave] = (unsigned)__popcll(m_rec); s_child[wave] = (unsigned)(__popcll(m_refl) + __popcll(m_refr)); }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1469,7 +1474,6 @@ __global__ void __launch_bounds__(RTC_WF_SHADE_BLOCK) wf_shade(DScene S, DCamera
     const unsigned s = s_rec[wave] + (unsigned)__popcll(m_rec & lt);
     const unsigned jr = s_child[wave] + (unsigned)__popcll(m_refl & lt);
     const unsigned jt = s_child[wave] + (unsigned)__popcll(m_refl) + (unsigned)__popcll(m_refr & lt);
-    __syncthreads();  // the next iteration reuses s_rec / s_child
     if (hit && s < W.cap) {
       double* r = W.sr[level & 1];
       r[s] = st.px; r[cap + s] = st.py; r[2 * cap + s] = st.pz;
