@@ -49,7 +49,7 @@
 #endif
 #endif
 #ifndef RTC_WF_SHADE_GRID_DIV
-#define RTC_WF_SHADE_GRID_DIV 4u
+#define RTC_WF_SHADE_GRID_DIV 2u
 #endif
 // per-lane BVH stacks live in LDS, sized per scene at launch (DScene.bvh_stack entries per lane)
 #ifdef RTC_EMU
@@ -1373,8 +1373,11 @@ __device__ __forceinline__ void wf_trace_ray(const DScene& S, const DCamera& cam
   W.h_n12[i] = n1; W.h_n12[cap + i] = n2;
 }
 
+#ifndef RTC_WF_SHADE_WAVES
+#define RTC_WF_SHADE_WAVES 4  // <= 128 VGPRs: two 512-thread blocks per CU, so one block's wait for its queue atomics is covered by the other
+#endif
 template <bool COUNT>
-__global__ void __launch_bounds__(RTC_WF_SHADE_BLOCK) wf_shade(DScene S, DCamera cam, DPixelMap pm, DWave W, int level, unsigned n0, int fuel0, DStats* __restrict__ stats) {
+__global__ void __launch_bounds__(RTC_WF_SHADE_BLOCK, RTC_WF_SHADE_WAVES) wf_shade(DScene S, DCamera cam, DPixelMap pm, DWave W, int level, unsigned n0, int fuel0, DStats* __restrict__ stats) {
   __shared__ unsigned s_rec2[2][16], s_child2[2][16];  // per wave: its count, then its base index in the queue (double-buffered
                                                        // by iteration parity: no barrier needed before the next iteration writes)
   unsigned parity = 0;
