@@ -82,6 +82,7 @@ struct Trav {
   double best_t;
   int best_prim, best_k, best_klast;
   int shadowed;
+  int unordered;  // any-hit pass that skips the nearest-first ordering of a node's children
   double c1_t, c2_t;
   int c1_prim, c2_prim;
   // per-ray cache of the reference's group box tests (groups 0..63): bit set in g_known once evaluated, in g_pass if it hit
@@ -448,7 +449,7 @@ __device__ __forceinline__ bool slab32c(float lx, float ly, float lz, float hx, 
 // becomes `cur`, the others are stacked; no hit pops (or ends the walk: cur = END).
 #define RTC_WALK_END ((int)0x80000000)
 __device__ __forceinline__ void node_step(const float4 lox, const float4 loy, const float4 loz, const float4 hix, const float4 hiy, const float4 hiz, const int4 cc,
-                                          const Frame32& F, float lo, float hi, int& cur, int& sp, int* __restrict__ stack, int stride) {
+                                          const Frame32& F, float lo, float hi, int& cur, int& sp, int* __restrict__ stack, int stride, bool any_hit) {
   const float FINF = __builtin_inff();
   float t0, t1, t2, t3;
   bool h0 = slab32c(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, F, lo, hi, t0);
@@ -459,6 +460,18 @@ __device__ __forceinline__ void node_step(const float4 lox, const float4 loy, co
   if (nh == 0) {
     if (sp == 0) cur = RTC_WALK_END;
     else { sp--; cur = stack[sp * stride]; }
+    return;
+  }
+  if (any_hit) {
+    // any-hit shadow pass (wave-uniform): the visiting order cannot change the answer, so no ordering work: the first hit
+    // child is walked next, the other hit children are stacked as they come
+    bool have = false;
+    int nxt = 0;
+    if (h0) { nxt = cc.x; have = true; }
+    if (h1) { if (have) { stack[sp * stride] = cc.y; sp++; } else { nxt = cc.y; have = true; } }
+    if (h2) { if (have) { stack[sp * stride] = cc.z; sp++; } else { nxt = cc.z; have = true; } }
+    if (h3) { if (have) { stack[sp * stride] = cc.w; sp++; } else { nxt = cc.w; have = true; } }
+    cur = nxt;
     return;
   }
   // order the (entry distance, child) pairs: a hit's key is finite (min with FLT_MAX also replaces a NaN), a miss's
@@ -482,6 +495,7 @@ __device__ __forceinline__ void bvh_walk(const DScene& S, int root, int frame, c
   Frame32 F;
   make_frame(kframe ? kframe : S.bvh_frame + 4 * frame, o, F);
   const int END = RTC_WALK_END;
+  const bool any_hit = T.mode == MODE_SHADOW_ANY && T.unordered;  // wavefront shadow role only: 3 % there, -2 % in the one-kernel path
   int sp = 0;
   int cur = root;
 #ifdef RTC_NO_KROOT
@@ -495,7 +509,7 @@ __device__ __forceinline__ void bvh_walk(const DScene& S, int root, int frame, c
     const float4 loz = {kroot->loz[0], kroot->loz[1], kroot->loz[2], kroot->loz[3]}, hix = {kroot->hix[0], kroot->hix[1], kroot->hix[2], kroot->hix[3]};
     const float4 hiy = {kroot->hiy[0], kroot->hiy[1], kroot->hiy[2], kroot->hiy[3]}, hiz = {kroot->hiz[0], kroot->hiz[1], kroot->hiz[2], kroot->hiz[3]};
     const int4 cc = {kroot->c[0], kroot->c[1], kroot->c[2], kroot->c[3]};
-    node_step(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride);
+    node_step(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride, any_hit);
   }
   for (;;) {
     DIAG_LOOP(0);
@@ -510,7 +524,7 @@ __device__ __forceinline__ void bvh_walk(const DScene& S, int root, int frame, c
       // the node's seven 16-byte rows: one line, all loads in flight together
       const float4 lox = ld4(N->lox), loy = ld4(N->loy), loz = ld4(N->loz), hix = ld4(N->hix), hiy = ld4(N->hiy), hiz = ld4(N->hiz);
       const int4 cc = ld4(N->c);
-      node_step(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride);
+      node_step(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride, any_hit);
     }
     if (cur == END) return;
     {
@@ -977,6 +991,7 @@ __device__ __forceinline__ void reset_closest(Trav& T, int mode) {
   T.tlo = 0.0; T.thi = DINF;
   T.best_t = DINF; T.best_prim = 0x7fffffff; T.best_k = 0; T.best_klast = 0;
   T.shadowed = 0;
+  T.unordered = 0;
   T.c1_t = 0.0; T.c2_t = 0.0; T.c1_prim = -1; T.c2_prim = -1;
   T.g_known = 0ull; T.g_pass = 0ull;
 }
@@ -1526,7 +1541,7 @@ __device__ __forceinline__ void wf_shadow_rec(const DScene& S, const DWave& W, i
     n_shadow++;
     Trav Sh;
     reset_closest(Sh, S.all_cast_shadow ? MODE_SHADOW_ANY : MODE_SHADOW_CLOSEST);
-    if (S.all_cast_shadow) Sh.thi = distance;
+    if (S.all_cast_shadow) { Sh.thi = distance; Sh.unordered = 1; }
     traverse<FEAT>(S, sray, Sh, C, stack, stride);
     bool shadowed;
     if (S.all_cast_shadow) shadowed = Sh.shadowed != 0;
