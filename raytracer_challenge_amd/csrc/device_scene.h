@@ -188,11 +188,12 @@ struct DStats {  // device-side counters (atomically accumulated per wave)
 
 #define RTC_MAX_FUEL 16
 
-// Wavefront path (rtc_kernels.hip, wf_* kernels): rays of one bounce level live in a queue; per level one closest-hit kernel,
-// one shading kernel (hit state, pattern colour, child rays into the other queue) and one shadow + lighting kernel run over
-// it, so the traversal kernels carry no shading state (half the registers of the one-kernel path -> twice the resident waves).
-// All arrays are SoA rows of `cap` elements.  A ray's colour contribution is stored per level and summed child -> parent in a
-// fixed order afterwards, so a pixel's value does not depend on what else was rendered with it.
+// Wavefront path (rtc_kernels.hip, wf_* kernels): rays of one bounce level live in a queue; per level a traversal launch
+// (closest hits of the level + shadow rays and lighting of the previous level) and a shading launch (hit state, pattern
+// colour, child rays into the other queue), so the traversal kernel carries no shading state (half the registers of the
+// one-kernel path -> twice the resident waves).  All arrays are SoA rows of `cap` elements.  A ray's colour contribution is
+// stored per level; wf_gather adds a pixel's contributions in the one-kernel path's depth-first order, so both paths give the
+// same bits and a pixel's value does not depend on what else was rendered with it.
 #define RTC_WF_SHADE_COUNT 32  // counts[RTC_WF_SHADE_COUNT + level] = shade records of the level
 #define RTC_WF_OVERFLOW 63     // counts[RTC_WF_OVERFLOW] != 0: a queue overflowed, the frame must be rendered by the one-kernel path
 #define RTC_WF_CHUNK_NEXT 64   // counts[RTC_WF_CHUNK_NEXT + 32 * (8 * launch + xcd)]: next chunk of traversal launch `launch` for blocks of

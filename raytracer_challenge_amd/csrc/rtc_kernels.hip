@@ -1306,25 +1306,14 @@ __global__ void __launch_bounds__(RTC_BLOCK, (FEAT >= 2 && RTC_WAVES_PER_SIMD < 
 
 // =================================================================================================================
 // Wavefront path (DWave in device_scene.h): the same device functions as rtc_trace_kernel, cut into per-level kernels.
-//   wf_trace   closest hit (+ container pass for transparent hits) of every ray of the level
+//   wf_ts      trace role: closest hit (+ container pass for transparent hits) of every ray of level d;
+//              shadow role: per shade record of level d - 1 and light, shadow ray + Phong terms -> the ray's colour contribution
 //   wf_shade   hit state, pattern colour -> shade record; reflected / refracted rays -> the other queue
-//   wf_shadow  per shade record and light: shadow ray + Phong terms -> the ray's colour contribution
 //   wf_gather  pixel = its ray tree's contributions, added in the one-kernel path's order (bit-identical results)
-// Every kernel is a grid-stride loop over a count that lives in device memory, so a frame is enqueued without host syncs.
+// Every kernel loops over counts that live in device memory, so a frame is enqueued without host syncs.
 // =================================================================================================================
 namespace {
 
-// Wave-aggregated queue push: one atomic per wave.  Every lane of the wave must call it (want = false for idle lanes).
-__device__ __forceinline__ unsigned wave_push(unsigned* counter, bool want) {
-  const unsigned long long m = __ballot(want ? 1 : 0);
-  if (m == 0ull) return 0xffffffffu;
-  const int lane = RTC_LANE_ID;
-  const int leader = __ffsll((long long)m) - 1;
-  unsigned base = 0;
-  if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(m));
-  base = __shfl(base, leader);
-  return want ? base + (unsigned)__popcll(m & ((1ull << lane) - 1ull)) : 0xffffffffu;
-}
 __device__ __forceinline__ unsigned wf_count(const DWave& W, int level, unsigned n0) {
   if (level == 0) return n0;
   unsigned c = W.counts[level];
