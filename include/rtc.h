@@ -127,19 +127,23 @@ typedef struct rtc_hit {
   int32_t push_idx;
 } rtc_hit;
 
-/* Work counters of one render call (deterministic for a given scene + accelerator). */
+/* Work counters of one render call (deterministic for a given scene + accelerator).  The *_kernarg counters say how many of
+ * the nodes / tests read their record from the kernel arguments (scalar loads): those move no bytes through the memory
+ * system and are excluded from bench.py's algorithmic-byte figure. */
 typedef struct rtc_stats {
   uint64_t pixels;
   uint64_t rays_primary, rays_shadow, rays_reflect, rays_refract; /* unique rays, SURVEY.md §8d */
-  uint64_t rays_container;   /* extra n1/n2 passes (device-internal, not counted as rays)  */
-  uint64_t accel_nodes;      /* accelerator BVH nodes fetched (64 B each)                  */
-  uint64_t group_tests;      /* reference group boxes tested (BoundingBox::intersects)     */
-  uint64_t tri_tests;        /* triangles tested (72 B each)                               */
-  uint64_t analytic_tests;   /* analytic primitives tested (112 B each)                    */
-  uint64_t nan_ts;           /* NaN intersection t's seen (-> RTC_ERR_NAN)                 */
+  uint64_t rays_container;   /* extra n1/n2 passes (device-internal, not counted as rays)                 */
+  uint64_t accel_nodes;      /* accelerator BVH nodes visited (4-wide nodes, 128 B each)                  */
+  uint64_t group_tests;      /* reference group boxes tested (BoundingBox::intersects; 48 B each)         */
+  uint64_t tri_tests;        /* triangles tested (72 B each)                                              */
+  uint64_t analytic_tests;   /* analytic primitives tested (one 128-B intersection record each)           */
+  uint64_t nan_ts;           /* NaN intersection t's seen since the last check (-> RTC_ERR_NAN)           */
   double kernel_ms;          /* device time of the trace kernel(s), HIP events on the scene's stream */
   uint32_t n_launches;
   uint32_t _pad;
+  uint64_t accel_nodes_kernarg;    /* of accel_nodes: root nodes read from the kernel arguments           */
+  uint64_t analytic_tests_kernarg; /* of analytic_tests: plane records read from the kernel arguments     */
 } rtc_stats;
 
 const char* rtc_last_error(void);
@@ -178,11 +182,13 @@ int rtc_quantize(rtc_scene*, const double* rgb, uint64_t n_values, uint8_t* out)
  * writes only if cap is large enough. */
 uint64_t rtc_ppm(uint64_t hsize, uint64_t vsize, const uint8_t* rgb8, char* out, uint64_t cap);
 
-/* Waits for the stream and returns the error state (RTC_ERR_NAN / RTC_ERR_DEVICE) of the LAST launch; asynchronous
- * launches (sync == 0, stats == NULL) do not report it themselves. */
+/* Waits for the stream and returns (and clears) the error state accumulated by EVERY launch since the last check or the last
+ * synchronous render: RTC_ERR_NAN / RTC_ERR_DEVICE / RTC_ERR_UNSUPPORTED (a wavefront queue overflowed in an unsynchronised
+ * launch).  Asynchronous launches (sync == 0, stats == NULL) do not report it themselves. */
 int rtc_scene_check(rtc_scene*);
 /* Stream markers for pipelined hosts: record marker `slot` (0..7) behind everything queued so far on the scene's stream;
- * wait for it on the host; device time between two recorded markers in ms. */
+ * wait for it on the host; device time between two recorded markers in ms.  RTC_ERR_INVALID for a slot outside 0..7 and for
+ * waiting on / measuring a slot that was never recorded. */
 int rtc_scene_record(rtc_scene*, int slot);
 int rtc_scene_wait(rtc_scene*, int slot);
 int rtc_scene_elapsed_ms(rtc_scene*, int slot_from, int slot_to, double* ms);
@@ -197,7 +203,8 @@ void rtc_scene_accel_info(const rtc_scene*, uint32_t* n_ops, uint32_t* n_bvh_nod
 /* Which device path renders whole-row launches of this scene (both give bit-identical pixels and hits):
  *   1  one kernel: a lane walks its pixel's whole ray tree (rtc_trace_kernel);
  *   4  wavefront: per bounce level a closest-hit + shadow kernel and a shading kernel over ray queues (wf_* kernels).
- * With the environment variable RTC_KERNEL unset the library measures: for one launch shape (camera, rows, fuel) the first
+ * RTC_KERNEL=1|4 pins a path for every launch of scenes created afterwards (pixel lists and explicit rays included: the parity
+ * tests run both).  With the environment variable RTC_KERNEL unset the library measures: for one launch shape (camera, rows, fuel) the first
  * four SYNCHRONOUS launches alternate between the paths (the smaller of a path's two device times counts: a first launch
  * pays for code loading and scratch), every later launch of that shape takes the faster.  Reports the state for
  * the most recent launch shape: *choice = 0 while undecided, else 1 or 4; the measured device times in ms (< 0 = not yet

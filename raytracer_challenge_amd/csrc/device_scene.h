@@ -23,6 +23,7 @@
 // The accelerator may only skip primitives whose exact test would not produce an intersection with t inside
 // the interval the current pass cares about, so hit records are independent of it.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 enum { OP_PRIM = 0, OP_GROUP = 1, OP_MESH = 2, OP_BVH = 3, OP_QUIRK = 4, OP_QGRID = 5, OP_CSG = 6, OP_CSG_END = 7 };
@@ -178,13 +179,20 @@ struct DCamera {
 };
 
 struct DStats {  // device-side counters (atomically accumulated per wave)
+  // per-launch counters: zeroed on the stream in front of every launch (the first RTC_STATS_LAUNCH_BYTES bytes)
   unsigned long long rays_primary, rays_shadow, rays_reflect, rays_refract, rays_container;
-  unsigned long long accel_nodes, group_tests, tri_tests, analytic_tests, nan_ts;
-  unsigned long long guard;  // bit mask of tripped traversal guards (0 = none)
+  unsigned long long accel_nodes, group_tests, tri_tests, analytic_tests;
+  unsigned long long knodes;    // of accel_nodes: BVH root nodes read from the kernel arguments (scalar loads, no memory traffic)
+  unsigned long long kplanes;   // of analytic_tests: plane records read from the kernel arguments
+  unsigned long long diag[32];  // RTC_DIAG builds only: region cycles / lane-utilisation sums (scripts/diag_report.py)
+  // sticky error state: accumulated over every launch since the last rtc_scene_check() / synchronous read-back, which clear it
+  unsigned long long nan_ts;       // NaN intersection t's seen (-> RTC_ERR_NAN)
+  unsigned long long guard;        // bit mask of tripped traversal guards (0 = none)
   unsigned long long guard_claim;  // first tripping lane claims the info slots
-  long long guard_info[8];
-  unsigned long long diag[32];  // RTC_DIAG builds only: region cycles / lane-utilisation sums (scripts/diag_report.py)   // code, it_kind, it, it_end, value, cur, pc, mode of the first trip
+  long long guard_info[8];         // code, it_kind, it, it_end, value, cur, pc, mode of the first trip
+  unsigned long long wf_overflow;  // a wavefront ray queue overflowed in some launch since the last check
 };
+#define RTC_STATS_LAUNCH_BYTES offsetof(DStats, nan_ts)
 
 #define RTC_MAX_FUEL 16
 

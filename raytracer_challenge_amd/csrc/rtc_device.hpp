@@ -1,0 +1,1486 @@
+// rtc_device.hpp — device functions and the templated ray kernels of the hot path (included by rtc_feat.hip, which
+// instantiates the kernels of ONE feature level per translation unit, and by rtc_kernels.hip).
+#pragma once
+
+// rtc_kernels.hip — hand-written HIP for gfx950 (MI355X): the reference's per-pixel path
+//   Image::par_render -> Camera::ray_at_pixel -> World::color_at -> {intersect, sort, hit, prepare_state,
+//   shade_hit -> {is_shadowed, Shape::lighting -> Pattern::color_at -> noise, reflected_color, refracted_color}}
+// (src/image.rs:65-81, src/camera.rs:39-55, src/world.rs:18-149, src/intersection.rs:24-139,
+//  src/shape.rs:414-462 + :592-946, src/bounding_box.rs:80-92, src/material.rs:164-302, src/noise.rs:31-237).
+//
+// All arithmetic is IEEE f64, compiled with -ffp-contract=off, in the reference's operation order wherever a
+// value can decide a hit.  What is *not* the reference's data flow:
+//   * no intersection lists, no sort: the nearest hit is the minimum of (t, primitive sequence, push index)
+//     over t >= 0 — exactly what "stable sort by t, first t >= 0" selects (src/intersection.rs:123-132);
+//   * n1/n2 (src/intersection.rs:70-103) come from one storage-free pass over the same ray: a shape is in the
+//     container list iff it has an odd number of intersections before the hit, and lists are ordered by each
+//     shape's last such intersection;
+//   * recursion (src/world.rs:84-132) is a per-lane stack of pending rays with scalar path weights; the
+//     reference's once-per-light re-tracing of identical subtrees (src/world.rs:58-79) becomes a factor L.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "device_scene.h"
+
+#define EPS 0.00001
+#ifndef RTC_BLOCK
+#define RTC_BLOCK 64
+#endif
+#ifndef RTC_WAVES_PER_SIMD
+#define RTC_WAVES_PER_SIMD 1
+#endif
+#ifdef RTC_TRAVERSE_NOINLINE
+#define TRAVERSE_INLINE __noinline__
+#else
+#define TRAVERSE_INLINE __forceinline__
+#endif
+#if defined(RTC_EMU) && !defined(RTC_EMU_SIMT)
+#define RTC_LANE_ID 0  // sequential emulation: every lane is its own wave
+#else
+#define RTC_LANE_ID ((int)(threadIdx.x & 63u))
+#endif
+// wf_shade reserves queue space once per block and iteration (same-address device atomics serialise: one per wave cost 0.4 ms
+// per level); the emulators run it with one-wave blocks
+#if defined(RTC_EMU) && !defined(RTC_EMU_SIMT)
+#define RTC_WF_SHADE_BLOCK 1
+#elif defined(RTC_EMU)
+#define RTC_WF_SHADE_BLOCK 64
+#else
+#ifndef RTC_WF_SHADE_BLOCK
+#define RTC_WF_SHADE_BLOCK 512  // measured: 128 -> +11 % frame time (more same-address atomics), 256 and 512 equal
+#endif
+#endif
+#ifndef RTC_WF_SHADE_GRID_DIV
+#define RTC_WF_SHADE_GRID_DIV 2u
+#endif
+// per-lane BVH stacks live in LDS, sized per scene at launch (DScene.bvh_stack entries per lane)
+#ifdef RTC_EMU
+#define RTC_LDS_STACK(name) static int name[RTC_BVH_STACK * RTC_BLOCK]
+#else
+#define RTC_LDS_STACK(name) extern __shared__ int name[]
+#endif
+#if defined(RTC_EMU) && !defined(RTC_EMU_SIMT)
+#define RTC_WF_LANES 1u
+#else
+#define RTC_WF_LANES 64u
+#endif
+#define DINF (__builtin_inf())
+static inline unsigned rtc_stack_bytes(const DScene& S) { return (unsigned)S.bvh_stack * RTC_BLOCK * (unsigned)sizeof(int); }
+
+namespace {
+
+struct Ray { double ox, oy, oz, dx, dy, dz; };
+
+enum { MODE_CLOSEST = 0, MODE_SHADOW_ANY = 1, MODE_SHADOW_CLOSEST = 2, MODE_CONTAINERS = 3 };
+
+// Per-ray traversal state (registers).  One layout serves all four passes:
+//   CLOSEST / SHADOW_CLOSEST: best_* = running minimum of (t, prim, push) over t >= 0; thi follows best_t.
+//   SHADOW_ANY: thi = distance to the light; `shadowed` set by any intersection with 0 <= t < thi.
+//   CONTAINERS: (thi, best_prim, best_klast) = key of the hit (left over from the closest pass);
+//               c1/c2 = odd-count shape with the largest (t, prim) before / up to that key (-1 = none).
+struct Trav {
+  int mode;
+  double tlo, thi;  // interval of t the pass cares about (also the accelerator's culling interval)
+  double best_t;
+  int best_prim, best_k, best_klast;
+  int shadowed;
+  int unordered;  // any-hit pass that skips the nearest-first ordering of a node's children
+  double c1_t, c2_t;
+  int c1_prim, c2_prim;
+  // per-ray cache of the reference's group box tests (groups 0..63): bit set in g_known once evaluated, in g_pass if it hit
+  unsigned long long g_known, g_pass;
+};
+
+struct Counters {
+  unsigned int accel_nodes, group_tests, tri_tests, analytic_tests, nan_ts;
+  unsigned int knodes, kplanes;  // of accel_nodes / analytic_tests: records that came from the kernel arguments (no memory traffic)
+};
+
+// ---- diagnostics (RTC_DIAG builds only; the shipped kernel compiles these to nothing) ----------------------------------
+// diag[2r] += cycles a lane spent in region r (every participating lane measures the wave's wall time of the region),
+// diag[2r+1] += 1 per participation; diag[16+2j] += active lanes, diag[16+2j+1] += 1 per executed iteration of loop j.
+#ifdef RTC_DIAG
+// accumulated per block in LDS (one wave per block: no cross-wave contention in the hot loops), flushed once at kernel end
+__shared__ unsigned long long s_diag[32];
+#define DIAG_T0() diag_t0_ = __builtin_amdgcn_s_memtime()
+#define DIAG_REGION(r) do { unsigned long long t1_ = __builtin_amdgcn_s_memtime(); atomicAdd(&s_diag[2 * (r)], t1_ - diag_t0_); atomicAdd(&s_diag[2 * (r) + 1], 1ull); diag_t0_ = t1_; } while (0)
+#define DIAG_SPAN_BEGIN() unsigned long long span_t0_ = __builtin_amdgcn_s_memtime()
+#define DIAG_SPAN_END(r) do { atomicAdd(&s_diag[2 * (r)], __builtin_amdgcn_s_memtime() - span_t0_); atomicAdd(&s_diag[2 * (r) + 1], 1ull); } while (0)
+#define DIAG_LOOP(j) do { unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) { s_diag[16 + 2 * (j)] += (unsigned long long)__popcll(m_); s_diag[16 + 2 * (j) + 1] += 1ull; } } while (0)
+#else
+#define DIAG_T0() do {} while (0)
+#define DIAG_REGION(r) do {} while (0)
+#define DIAG_SPAN_BEGIN() do {} while (0)
+#define DIAG_SPAN_END(r) do {} while (0)
+#define DIAG_LOOP(j) do {} while (0)
+#endif
+
+// Rust f64::max/min: a NaN operand is ignored.
+__device__ __forceinline__ double rmax(double a, double b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
+__device__ __forceinline__ double rmin(double a, double b) { return (a != a) ? b : ((b != b) ? a : (a < b ? a : b)); }
+
+// src/shape.rs:635-653
+__device__ __forceinline__ void cube_axis(double origin, double direction, double mn, double mx, double& tmin, double& tmax) {
+  double a_num = mn - origin, b_num = mx - origin;
+  double a, b;
+  if (fabs(direction) >= EPS) {
+    a = a_num / direction;
+    b = b_num / direction;
+  } else {
+    a = a_num * DINF;
+    b = b_num * DINF;
+  }
+  if (a > b) { tmin = b; tmax = a; } else { tmin = a; tmax = b; }
+}
+
+// src/bounding_box.rs:80-92 on the group's f64 box
+__device__ __forceinline__ bool group_box_hit(const double* __restrict__ b, const Ray& r) {
+  double xa, xb, ya, yb, za, zb;
+  cube_axis(r.ox, r.dx, b[0], b[3], xa, xb);
+  cube_axis(r.oy, r.dy, b[1], b[4], ya, yb);
+  cube_axis(r.oz, r.dz, b[2], b[5], za, zb);
+  double t_min = rmax(rmax(xa, ya), za);
+  double t_max = rmin(rmin(xb, yb), zb);
+  return t_min <= t_max;
+}
+
+// Group::intersect's gate (src/shape.rs:251): a primitive (mesh, CSG node) under aggregation groups is reached only if
+// BoundingBox::intersects passes for every ancestor.  g = innermost group; walks group_parent; results cached per ray.
+template <bool CACHE = true>
+__device__ __forceinline__ bool groups_pass(const DScene& S, int g, const Ray& r, Trav& T, Counters& C) {
+  while (g >= 0) {
+    bool hit;
+    if (CACHE && g < 64) {
+      const unsigned long long bit = 1ull << g;
+      if (T.g_known & bit) hit = (T.g_pass & bit) != 0ull;
+      else {
+        C.group_tests++;
+        hit = group_box_hit(S.group_box + 6 * g, r);
+        T.g_known |= bit;
+        if (hit) T.g_pass |= bit;
+      }
+    } else {
+      C.group_tests++;
+      hit = group_box_hit(S.group_box + 6 * g, r);
+    }
+    if (!hit) return false;
+    g = S.group_parent[g];
+  }
+  return true;
+}
+
+// Ray::transform (src/ray.rs:14-19) with Matrix*Vector (src/linalg/matrix.rs:261-284); origin.w = 1, direction.w = 0.
+__device__ __forceinline__ Ray to_object(const double* __restrict__ m, const Ray& r) {
+  Ray o;
+  o.ox = m[0] * r.ox + m[1] * r.oy + m[2] * r.oz + m[3] * 1.0;
+  o.oy = m[4] * r.ox + m[5] * r.oy + m[6] * r.oz + m[7] * 1.0;
+  o.oz = m[8] * r.ox + m[9] * r.oy + m[10] * r.oz + m[11] * 1.0;
+  o.dx = m[0] * r.dx + m[1] * r.dy + m[2] * r.dz + m[3] * 0.0;
+  o.dy = m[4] * r.dx + m[5] * r.dy + m[6] * r.dz + m[7] * 0.0;
+  o.dz = m[8] * r.dx + m[9] * r.dy + m[10] * r.dz + m[11] * 0.0;
+  return o;
+}
+
+// ---- feeding intersections of ONE primitive (in push order) to the current pass ------------------------
+__device__ __forceinline__ bool key_before(double t, int prim, int k, double ht, int hprim, int hk) {
+  return (t < ht) || (t == ht && (prim < hprim || (prim == hprim && k < hk)));
+}
+
+// `ks` (optional) = the original push index of each entry, when a CSG filter has dropped some of a primitive's pushes.
+__device__ __forceinline__ void accept(Trav& T, Counters& C, int prim, int n, const double* t, const int* ks = nullptr) {
+  if (n == 0) return;
+  if (T.mode == MODE_CLOSEST || T.mode == MODE_SHADOW_CLOSEST) {
+    for (int j = 0; j < n; j++) {
+      const int k = ks ? ks[j] : j;
+      double tk = t[j];
+      if (tk != tk) C.nan_ts++;
+      if (tk >= 0.0) {
+        if (tk < T.best_t || (tk == T.best_t && prim < T.best_prim)) {
+          T.best_t = tk; T.best_prim = prim; T.best_k = k; T.best_klast = k;
+          T.thi = tk;
+        } else if (tk == T.best_t && prim == T.best_prim) {
+          T.best_klast = k;
+        }
+      }
+    }
+  } else if (T.mode == MODE_SHADOW_ANY) {
+    for (int k = 0; k < n; k++) {
+      double tk = t[k];
+      if (tk != tk) C.nan_ts++;
+      if (tk >= 0.0 && tk < T.thi) T.shadowed = 1;
+    }
+  } else {  // MODE_CONTAINERS
+    int cnt1 = 0, cnt2 = 0;
+    double m1 = 0.0, m2 = 0.0;
+    for (int j = 0; j < n; j++) {
+      const int k = ks ? ks[j] : j;
+      double tk = t[j];
+      bool b1 = key_before(tk, prim, k, T.thi, T.best_prim, T.best_klast);
+      bool b2 = b1 || (tk == T.thi && prim == T.best_prim && k == T.best_klast);
+      // pushes of one primitive arrive in push order, so ">=" keeps the latest push among equal t
+      if (b1) { if (cnt1 == 0 || tk >= m1) m1 = tk; cnt1++; }
+      if (b2) { if (cnt2 == 0 || tk >= m2) m2 = tk; cnt2++; }
+    }
+    if ((cnt1 & 1) && (T.c1_prim < 0 || m1 > T.c1_t || (m1 == T.c1_t && prim > T.c1_prim))) { T.c1_t = m1; T.c1_prim = prim; }
+    if ((cnt2 & 1) && (T.c2_prim < 0 || m2 > T.c2_t || (m2 == T.c2_t && prim > T.c2_prim))) { T.c2_t = m2; T.c2_prim = prim; }
+  }
+}
+
+// Geometry::intersect_triangle (src/shape.rs:824-860); o = object-space ray
+__device__ __forceinline__ int tri_hit(const double* __restrict__ g, const Ray& o, double& t, double& u, double& v) {
+  double p1x = g[0], p1y = g[1], p1z = g[2], e1x = g[3], e1y = g[4], e1z = g[5], e2x = g[6], e2y = g[7], e2z = g[8];
+  double cx = o.dy * e2z - o.dz * e2y, cy = o.dz * e2x - o.dx * e2z, cz = o.dx * e2y - o.dy * e2x;  // dir x e2
+  double det = e1x * cx + e1y * cy + e1z * cz;
+  if (fabs(det) < EPS) return 0;
+  double f = 1.0 / det;
+  double sx = o.ox - p1x, sy = o.oy - p1y, sz = o.oz - p1z;  // p1_to_origin
+  u = f * (sx * cx + sy * cy + sz * cz);
+  if (u < 0.0 || u > 1.0) return 0;
+  double qx = sy * e1z - sz * e1y, qy = sz * e1x - sx * e1z, qz = sx * e1y - sy * e1x;  // origin x e1
+  v = f * (o.dx * qx + o.dy * qy + o.dz * qz);
+  if (v < 0.0 || u + v > 1.0) return 0;
+  t = f * (e2x * qx + e2y * qy + e2z * qz);
+  return 1;
+}
+
+// Geometry::intersect (src/shape.rs:862-885) for one primitive; returns the number of pushes, in push order.
+__device__ __forceinline__ int prim_hits(const DScene& S, const DPrimI& P, const Ray& o, double* t, double& u, double& v) {
+  int n = 0;
+  switch (P.geom) {
+    case 0: {  // sphere :592-619
+      double a = o.dx * o.dx + o.dy * o.dy + o.dz * o.dz;
+      double b = 2.0 * (o.dx * o.ox + o.dy * o.oy + o.dz * o.oz);
+      double c = (o.ox * o.ox + o.oy * o.oy + o.oz * o.oz) - 1.0;
+      double disc = b * b - 4.0 * a * c;
+      if (disc < 0.0) return 0;
+      double sq = sqrt(disc);
+      t[0] = (-b - sq) / (2.0 * a);
+      t[1] = (-b + sq) / (2.0 * a);
+      return 2;
+    }
+    case 1: {  // plane :621-633
+      if (fabs(o.dy - 0.0) < EPS) return 0;
+      t[0] = -o.oy / o.dy;
+      return 1;
+    }
+    case 2: {  // cube :655-679
+      double xa, xb, ya, yb, za, zb;
+      cube_axis(o.ox, o.dx, -1.0, 1.0, xa, xb);
+      cube_axis(o.oy, o.dy, -1.0, 1.0, ya, yb);
+      cube_axis(o.oz, o.dz, -1.0, 1.0, za, zb);
+      double t_min = rmax(rmax(xa, ya), za);
+      double t_max = rmin(rmin(xb, yb), zb);
+      if (t_min <= t_max) { t[0] = t_min; t[1] = t_max; return 2; }
+      return 0;
+    }
+    case 3:
+    case 4: {  // cylinder :724-768, cone :770-822
+      double mn = P.mn, mx = P.mx;
+      bool cone = P.geom == 4;
+      double a, b, c;
+      bool walls;
+      if (!cone) {
+        a = o.dx * o.dx + o.dz * o.dz;
+        walls = !(fabs(a - 0.0) < EPS);
+        b = 2.0 * o.ox * o.dx + 2.0 * o.oz * o.dz;
+        c = o.ox * o.ox + o.oz * o.oz - 1.0;
+      } else {
+        a = o.dx * o.dx - o.dy * o.dy + o.dz * o.dz;
+        b = 2.0 * o.ox * o.dx - 2.0 * o.oy * o.dy + 2.0 * o.oz * o.dz;
+        c = o.ox * o.ox - o.oy * o.oy + o.oz * o.oz;
+        bool a0 = fabs(a - 0.0) < EPS, b0 = fabs(b - 0.0) < EPS;
+        walls = !a0;
+        if (a0 && !b0) t[n++] = -c / (2.0 * b);  // single-root branch :812-818
+      }
+      if (walls) {
+        double disc = b * b - 4.0 * a * c;
+        if (disc >= 0.0) {
+          double sq = sqrt(disc);
+          double t0 = (-b - sq) / (2.0 * a);
+          double y0 = o.oy + t0 * o.dy;
+          if (mn < y0 && y0 < mx) t[n++] = t0;
+          double t1 = (-b + sq) / (2.0 * a);
+          double y1 = o.oy + t1 * o.dy;
+          if (mn < y1 && y1 < mx) t[n++] = t1;
+        }
+      }
+      // intersect_cap :681-722 (cylinder radii 1,1; cone radii min,max)
+      if ((P.flags & 2u) && !(fabs(o.dy - 0.0) < EPS)) {
+        double r0 = cone ? mn : 1.0, r1 = cone ? mx : 1.0;
+        double tc = (mn - o.oy) / o.dy;
+        double x = o.ox + tc * o.dx, z = o.oz + tc * o.dz;
+        if ((x * x + z * z) <= r0 * r0) t[n++] = tc;
+        tc = (mx - o.oy) / o.dy;
+        x = o.ox + tc * o.dx; z = o.oz + tc * o.dz;
+        if ((x * x + z * z) <= r1 * r1) t[n++] = tc;
+      }
+      return n;
+    }
+    default:  // triangles :824-860
+      return tri_hit(S.tri_geo + 9 * P.data, o, t[0], u, v);
+  }
+}
+
+// Shape::intersect (src/shape.rs:414-417) for one primitive.
+// Two reference quirks let a primitive report an intersection OUTSIDE any finite bound of its surface, so a
+// bounding-volume hierarchy alone would lose them:
+//   cube: an axis with |direction| < EPSILON only requires the ORIGIN to be inside the slab (src/shape.rs:641-648);
+//   cone: when a ~ 0 the single root -c/(2b) is pushed without the min < y < max check (src/shape.rs:812-818).
+// Rays in that state ("quirk rays" for this primitive) are tested by the linear OP_QUIRK pass and skipped in
+// the BVH leaf; all other rays are tested in the leaf only.  policy: 0 always, 1 skip if quirk, 2 only if quirk.
+// FEAT: feature level of the kernel instantiation — 0: no groups, no CSG in the scene (no gate code at all); 1: only whole
+// meshes are gated (one uncached chain walk per OP_MESH: the teapot scenes); 2: per-primitive gates with the per-ray cache;
+// 3: + CSG.  Keeps the common kernels under the register cliff.
+template <int FEAT>
+__device__ __forceinline__ void visit_prim(const DScene& S, int prim, const Ray& r, Trav& T, Counters& C, int policy) {
+  const DPrimI P = S.pisect[prim];
+  if (FEAT >= 2 && P.gcond >= 0 && !groups_pass(S, P.gcond, r, T, C)) return;
+  const double* __restrict__ m = P.m;
+  if (P.geom == 1) {
+    // Plane (src/shape.rs:621-633) only reads origin.y and direction.y of the object-space ray: evaluate that one row of
+    // Ray::transform, in the same order, and skip the other two.
+    C.analytic_tests++;
+    double oy = m[4] * r.ox + m[5] * r.oy + m[6] * r.oz + m[7] * 1.0;
+    double dy = m[4] * r.dx + m[5] * r.dy + m[6] * r.dz + m[7] * 0.0;
+    if (fabs(dy - 0.0) < EPS) return;
+    double t = -oy / dy;
+    accept(T, C, prim, 1, &t);
+    return;
+  }
+  if (policy == 2) {
+    // quirk scan: the condition needs the object-space DIRECTION only; most candidates are rejected here
+    double dx = m[0] * r.dx + m[1] * r.dy + m[2] * r.dz + m[3] * 0.0;
+    double dy = m[4] * r.dx + m[5] * r.dy + m[6] * r.dz + m[7] * 0.0;
+    double dz = m[8] * r.dx + m[9] * r.dy + m[10] * r.dz + m[11] * 0.0;
+    bool quirk = false;
+    if (P.geom == 2) quirk = fabs(dx) < EPS || fabs(dy) < EPS || fabs(dz) < EPS;
+    else if (P.geom == 4) quirk = fabs((dx * dx - dy * dy + dz * dz) - 0.0) < EPS;
+    if (!quirk) return;
+  }
+  Ray o = to_object(m, r);
+  if (policy == 1) {
+    bool quirk = false;
+    if (P.geom == 2) quirk = fabs(o.dx) < EPS || fabs(o.dy) < EPS || fabs(o.dz) < EPS;
+    else if (P.geom == 4) quirk = fabs((o.dx * o.dx - o.dy * o.dy + o.dz * o.dz) - 0.0) < EPS;
+    if (quirk) return;
+  }
+  double t[4], u = 0.0, v = 0.0;
+  if (P.geom >= 5) C.tri_tests++; else C.analytic_tests++;
+  int n = prim_hits(S, P, o, t, u, v);
+  accept(T, C, prim, n, t);
+}
+
+// Direction-grid culled quirk scan (device_scene.h OP_QGRID).  The cell lookup must mirror build_quirk_grid().
+template <int FEAT>
+__device__ __forceinline__ void quirk_grid_scan(const DScene& S, const DQuirkGrid G, const Ray& r, Trav& T, Counters& C) {
+  double ax = fabs(r.dx), ay = fabs(r.dy), az = fabs(r.dz);
+  double len2 = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
+  if (!(len2 >= RTC_QGRID_MIN_LEN * RTC_QGRID_MIN_LEN) || !(len2 < DINF)) {
+    for (int i = G.lin_first; i < G.lin_first + G.lin_count; i++) visit_prim<FEAT>(S, S.quirk_prim[i], r, T, C, 2);
+    return;
+  }
+  int face;
+  double u, v;
+  if (ax >= ay && ax >= az) { face = r.dx > 0.0 ? 0 : 1; u = r.dy / ax; v = r.dz / ax; }
+  else if (ay >= az) { face = r.dy > 0.0 ? 2 : 3; u = r.dx / ay; v = r.dz / ay; }
+  else { face = r.dz > 0.0 ? 4 : 5; u = r.dx / az; v = r.dy / az; }
+  int iu = (int)((u + 1.0) * 0.5 * (double)G.n), iv = (int)((v + 1.0) * 0.5 * (double)G.n);
+  iu = iu < 0 ? 0 : (iu >= G.n ? G.n - 1 : iu);
+  iv = iv < 0 ? 0 : (iv >= G.n ? G.n - 1 : iv);
+  int cell = G.cell_off + (face * G.n + iv) * G.n + iu;
+  unsigned b = S.qcell[cell], e = S.qcell[cell + 1];
+  for (unsigned i = b; i < e; i++) visit_prim<FEAT>(S, S.qitem[i], r, T, C, 2);
+}
+
+// ---- accelerator -------------------------------------------------------------------------------------
+// ---- f32 slab test in the BVH's own frame (culling only) ------------------------------------------------
+// Node boxes are f32, stored relative to the BVH's centre c and already widened at build time.  Per ray and BVH:
+//   of  = fl32(o - c)                     (the f64 subtraction is exact to 2^-53, the rounding to f32 costs 2^-24 |o - c|)
+//   eps = 2^-20 (|of|_inf + R)            R = radius of the BVH around c: >= 16x every f32 rounding error of the test,
+//                                         each of which is bounded by 2^-23 times a coordinate or a distance travelled
+//   every box is inflated by eps by testing its low faces against of + eps and its high faces against of - eps,
+//   and the pass's t interval is widened by 2^-18 relative.
+// So a box is rejected only if the f64 ray misses the box inflated by ~15 eps or its [tn, tf] misses [t_lo, t_hi]; NaN
+// (0 * inf) operands are ignored by fminf/fmaxf exactly as in the f64 version.  A ray whose origin does not fit f32
+// relative to c takes every box (id = 0 makes every slab interval [0, 0]).
+struct Frame32 {
+  float olx, oly, olz, ohx, ohy, ohz, ix, iy, iz;
+};
+__device__ __forceinline__ void make_frame(const double* __restrict__ fr, const Ray& o, Frame32& f) {
+  float ox = (float)(o.ox - fr[0]), oy = (float)(o.oy - fr[1]), oz = (float)(o.oz - fr[2]);
+  float m = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + (float)fr[3];
+  if (!(m < 1e30f)) {
+    f.olx = f.oly = f.olz = f.ohx = f.ohy = f.ohz = 0.0f;
+    f.ix = f.iy = f.iz = 0.0f;
+    return;
+  }
+  float eps = m * 9.5367431640625e-07f + 1e-30f;
+  f.olx = ox + eps; f.oly = oy + eps; f.olz = oz + eps;
+  f.ohx = ox - eps; f.ohy = oy - eps; f.ohz = oz - eps;
+  f.ix = 1.0f / (float)o.dx; f.iy = 1.0f / (float)o.dy; f.iz = 1.0f / (float)o.dz;
+}
+__device__ __forceinline__ void t_interval32(const Trav& T, float& lo, float& hi) {
+  const double SL = 3.814697265625e-06;  // 2^-18
+  lo = (T.tlo == -DINF) ? -__builtin_inff() : (float)(T.tlo - SL * fmax(fabs(T.tlo), 1.0));
+  hi = (T.thi == DINF) ? __builtin_inff() : (float)(T.thi + SL * fmax(fabs(T.thi), 1.0));
+}
+__device__ __forceinline__ bool slab32(const float* __restrict__ lo, const float* __restrict__ hi, const Frame32& f, float tlo, float thi, float& tn_out) {
+  float t0 = (lo[0] - f.olx) * f.ix, t1 = (hi[0] - f.ohx) * f.ix;
+  float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+  t0 = (lo[1] - f.oly) * f.iy; t1 = (hi[1] - f.ohy) * f.iy;
+  tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+  t0 = (lo[2] - f.olz) * f.iz; t1 = (hi[2] - f.ohz) * f.iz;
+  tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+  tn_out = tn;
+  return fmaxf(tn, tlo) <= fminf(tf, thi) && lo[0] <= hi[0];
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { float4 v; __builtin_memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ int4 ld4(const int32_t* p) { int4 v; __builtin_memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ bool slab32c(float lx, float ly, float lz, float hx, float hy, float hz, const Frame32& f, float tlo, float thi, float& tn_out) {
+  float t0 = (lx - f.olx) * f.ix, t1 = (hx - f.ohx) * f.ix;
+  float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+  t0 = (ly - f.oly) * f.iy; t1 = (hy - f.ohy) * f.iy;
+  tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+  t0 = (lz - f.olz) * f.iz; t1 = (hz - f.ohz) * f.iz;
+  tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+  tn_out = tn;
+  return fmaxf(tn, tlo) <= fminf(tf, thi) && lx <= hx;
+}
+
+// One inner-node step of the walk: the node's four child boxes against the ray; hits ordered nearest first, the nearest
+// becomes `cur`, the others are stacked; no hit pops (or ends the walk: cur = END).
+#define RTC_WALK_END ((int)0x80000000)
+__device__ __forceinline__ void node_step(const float4 lox, const float4 loy, const float4 loz, const float4 hix, const float4 hiy, const float4 hiz, const int4 cc,
+                                          const Frame32& F, float lo, float hi, int& cur, int& sp, int* __restrict__ stack, int stride, bool any_hit) {
+  const float FINF = __builtin_inff();
+  float t0, t1, t2, t3;
+  bool h0 = slab32c(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, F, lo, hi, t0);
+  bool h1 = slab32c(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, F, lo, hi, t1);
+  bool h2 = slab32c(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, F, lo, hi, t2);
+  bool h3 = slab32c(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, F, lo, hi, t3);
+  const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+  if (nh == 0) {
+    if (sp == 0) cur = RTC_WALK_END;
+    else { sp--; cur = stack[sp * stride]; }
+    return;
+  }
+  if (any_hit) {
+    // any-hit shadow pass (wave-uniform): the visiting order cannot change the answer, so no ordering work: the first hit
+    // child is walked next, the other hit children are stacked as they come
+    bool have = false;
+    int nxt = 0;
+    if (h0) { nxt = cc.x; have = true; }
+    if (h1) { if (have) { stack[sp * stride] = cc.y; sp++; } else { nxt = cc.y; have = true; } }
+    if (h2) { if (have) { stack[sp * stride] = cc.z; sp++; } else { nxt = cc.z; have = true; } }
+    if (h3) { if (have) { stack[sp * stride] = cc.w; sp++; } else { nxt = cc.w; have = true; } }
+    cur = nxt;
+    return;
+  }
+  // order the (entry distance, child) pairs: a hit's key is finite (min with FLT_MAX also replaces a NaN), a miss's
+  // is +inf, so after the network the first nh pairs are exactly the hits, nearest first
+  const float FMAXV = 3.4028234663852886e38f;
+  t0 = h0 ? fminf(t0, FMAXV) : FINF; t1 = h1 ? fminf(t1, FMAXV) : FINF; t2 = h2 ? fminf(t2, FMAXV) : FINF; t3 = h3 ? fminf(t3, FMAXV) : FINF;
+  int c0 = cc.x, c1 = cc.y, c2 = cc.z, c3 = cc.w;
+#define RTC_CSWAP(ta, ca, tb, cb) { const bool s_ = tb < ta; const float tt_ = s_ ? tb : ta; const int ct_ = s_ ? cb : ca; tb = s_ ? ta : tb; cb = s_ ? ca : cb; ta = tt_; ca = ct_; }
+  RTC_CSWAP(t0, c0, t1, c1) RTC_CSWAP(t2, c2, t3, c3) RTC_CSWAP(t0, c0, t2, c2) RTC_CSWAP(t1, c1, t3, c3) RTC_CSWAP(t1, c1, t2, c2)
+#undef RTC_CSWAP
+  if (nh > 3) { stack[sp * stride] = c3; sp++; }
+  if (nh > 2) { stack[sp * stride] = c2; sp++; }
+  if (nh > 1) { stack[sp * stride] = c1; sp++; }
+  cur = c0;
+}
+
+// kroot / kframe: the root node and the frame of this BVH from the kernel arguments (DScene.kaux; scalar loads) or nullptr.
+template <bool MESH, int FEAT>
+__device__ __forceinline__ void bvh_walk(const DScene& S, int root, int frame, const Ray& world, const Ray& o, Trav& T, Counters& C, int* __restrict__ stack, int stride,
+                                         const DBvhNode4* kroot = nullptr, const double* kframe = nullptr) {
+  Frame32 F;
+  make_frame(kframe ? kframe : S.bvh_frame + 4 * frame, o, F);
+  const int END = RTC_WALK_END;
+  const bool any_hit = T.mode == MODE_SHADOW_ANY && T.unordered;  // wavefront shadow role only: 3 % there, -2 % in the one-kernel path
+  int sp = 0;
+  int cur = root;
+#ifdef RTC_NO_KROOT
+  kroot = nullptr;
+#endif
+  if (kroot) {  // every lane starts at the root: its boxes come from the kernel arguments
+    C.accel_nodes++;
+    C.knodes++;
+    float lo, hi;
+    t_interval32(T, lo, hi);
+    const float4 lox = {kroot->lox[0], kroot->lox[1], kroot->lox[2], kroot->lox[3]}, loy = {kroot->loy[0], kroot->loy[1], kroot->loy[2], kroot->loy[3]};
+    const float4 loz = {kroot->loz[0], kroot->loz[1], kroot->loz[2], kroot->loz[3]}, hix = {kroot->hix[0], kroot->hix[1], kroot->hix[2], kroot->hix[3]};
+    const float4 hiy = {kroot->hiy[0], kroot->hiy[1], kroot->hiy[2], kroot->hiy[3]}, hiz = {kroot->hiz[0], kroot->hiz[1], kroot->hiz[2], kroot->hiz[3]};
+    const int4 cc = {kroot->c[0], kroot->c[1], kroot->c[2], kroot->c[3]};
+    node_step(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride, any_hit);
+  }
+  for (;;) {
+    DIAG_LOOP(0);
+    // "while-while": descend through inner nodes until this lane holds a leaf (or has drained its stack); lanes that
+    // already hold a leaf wait here, so the expensive leaf tests below run with as many lanes as possible.
+    while (cur >= 0) {
+      DIAG_LOOP(3);
+      const DBvhNode4* N = S.bvh + cur;
+      C.accel_nodes++;
+      float lo, hi;
+      t_interval32(T, lo, hi);
+      // the node's seven 16-byte rows: one line, all loads in flight together
+      const float4 lox = ld4(N->lox), loy = ld4(N->loy), loz = ld4(N->loz), hix = ld4(N->hix), hiy = ld4(N->hiy), hiz = ld4(N->hiz);
+      const int4 cc = ld4(N->c);
+      node_step(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride, any_hit);
+    }
+    if (cur == END) return;
+    {
+      DIAG_SPAN_BEGIN();
+      int first = (~cur) >> 3, cnt = ((~cur) & 7) + 1;
+      if (MESH) {
+        for (int i = first; i < first + cnt; i++) {
+          DIAG_LOOP(1);
+          double t, u, v;
+          C.tri_tests++;
+          if (tri_hit(S.mtri + 9 * (size_t)i, o, t, u, v)) accept(T, C, S.mtri_prim[i], 1, &t);
+        }
+      } else {
+        DIAG_LOOP(1);
+        visit_prim<FEAT>(S, first, world, T, C, 1);  // analytic leaf = one primitive, named by the ref itself
+      }
+      DIAG_SPAN_END(6);
+      if (T.mode == MODE_SHADOW_ANY && T.shadowed) return;
+    }
+    if (sp == 0) return;
+    sp--;
+    cur = stack[sp * stride];
+  }
+}
+
+// ---- CSG groups (src/shape.rs:161-178 allows_intersection, :230-246 filter_by_group, :257-266 Group::intersect) ------------
+// ops[pc] is an OP_CSG.  The subtree's sub-program is walked once; every primitive's pushes go to a per-lane buffer in
+// insertion order; at each OP_CSG_END the node's range of the buffer is stable-sorted by t and filtered in place — post-order,
+// so a nested CSG hands its parent exactly the list the reference's recursion would.  What survives the outermost filter is
+// fed to the current pass with each entry's own (primitive, push index), so tie-breaks and the container pass see the same keys.
+struct CsgHit { double t; int prim, k; };
+__device__ __noinline__ int csg_eval(const DScene& S, int pc, const Ray& r, Trav& T, Counters& C) {
+  CsgHit buf[RTC_CSG_MAX_HITS];
+  int n = 0;
+  int frame_begin[RTC_CSG_MAX_DEPTH];
+  int depth = 0;
+  const int end_pc = S.ops[pc].b;  // the matching OP_CSG_END
+  int p = pc;
+  while (p <= end_pc) {
+    DOp op = S.ops[p];
+    if (op.op == OP_CSG) {
+      C.group_tests++;
+      if (!group_box_hit(S.group_box + 6 * op.a, r)) { p = op.b + 1; continue; }  // whole node contributes nothing
+      frame_begin[depth++] = n;
+      p++;
+    } else if (op.op == OP_GROUP) {
+      C.group_tests++;
+      p = group_box_hit(S.group_box + 6 * op.a, r) ? p + 1 : op.b;
+    } else if (op.op == OP_PRIM) {
+      const DPrimI P = S.pisect[op.a];
+      Ray o = to_object(P.m, r);
+      double t[4], u = 0.0, v = 0.0;
+      if (P.geom >= 5) C.tri_tests++; else C.analytic_tests++;
+      int m = prim_hits(S, P, o, t, u, v);
+      for (int j = 0; j < m && n < RTC_CSG_MAX_HITS; j++) {
+        if (t[j] != t[j]) C.nan_ts++;  // the reference sorts this list: a NaN t panics (src/intersection.rs:124)
+        buf[n].t = t[j]; buf[n].prim = op.a; buf[n].k = j; n++;
+      }
+      p++;
+    } else {  // OP_CSG_END: sort [b, n) by t (stable: insertion sort), then filter_by_group
+      const DCsg G = S.csg[op.c];
+      int b = frame_begin[--depth];
+      for (int i = b + 1; i < n; i++) {
+        CsgHit h = buf[i];
+        int j = i - 1;
+        while (j >= b && buf[j].t > h.t) { buf[j + 1] = buf[j]; j--; }
+        buf[j + 1] = h;
+      }
+      bool in_left = false, in_right = false;
+      int w = b;
+      for (int i = b; i < n; i++) {
+        bool left_hit = buf[i].prim >= G.left_first && buf[i].prim < G.left_end;
+        bool keep;
+        if (G.kind == 0) keep = (left_hit && !in_right) || (!left_hit && !in_left);         // Union
+        else if (G.kind == 1) keep = (left_hit && in_right) || (!left_hit && in_left);      // Intersection
+        else keep = (left_hit && !in_right) || (!left_hit && in_left);                      // Difference
+        if (left_hit) in_left = !in_left; else in_right = !in_right;
+        if (keep) buf[w++] = buf[i];
+      }
+      n = w;
+      p++;
+    }
+  }
+  // hand the retained intersections to the pass, one primitive at a time (its entries keep their relative order)
+  for (int i = 0; i < n; i++) {
+    int prim = buf[i].prim;
+    bool seen = false;
+    for (int j = 0; j < i; j++) seen = seen || buf[j].prim == prim;
+    if (seen) continue;
+    double t[8];
+    int ks[8], m = 0;
+    for (int j = i; j < n && m < 8; j++)
+      if (buf[j].prim == prim) { t[m] = buf[j].t; ks[m] = buf[j].k; m++; }
+    accept(T, C, prim, m, t, ks);
+  }
+  return end_pc + 1;
+}
+
+// World::intersect (src/world.rs:18-24) + Group::intersect (src/shape.rs:248-269) over the flattened program.
+// CSGK: the kernel instantiation for scenes that contain CSG groups; all others never see the (register-hungry) call.
+template <int FEAT>
+__device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T, Counters& C, int* __restrict__ stack, int stride) {
+  if (FEAT <= 1 && S.n_kops > 0) {
+    // short jump-free program from the kernel arguments: pc is wave-uniform, the op and the plane records are scalar loads
+    for (int pc = 0; pc < S.n_kops; pc++) {
+      DIAG_LOOP(2);
+      const DOp op = S.kops[pc];
+      if (op.op == OP_PRIM) {
+        if (op.c >= 0) {
+          // Plane (src/shape.rs:621-633): the same row-1 evaluation as visit_prim's plane case, operands from kernargs
+          const DPlaneK P = S.kplanes[op.c];
+          C.analytic_tests++;
+          C.kplanes++;
+          double oy = P.row[0] * r.ox + P.row[1] * r.oy + P.row[2] * r.oz + P.row[3] * 1.0;
+          double dy = P.row[0] * r.dx + P.row[1] * r.dy + P.row[2] * r.dz + P.row[3] * 0.0;
+          if (!(fabs(dy - 0.0) < EPS)) {
+            double t = -oy / dy;
+            accept(T, C, P.prim, 1, &t);
+          }
+        } else {
+          visit_prim<FEAT>(S, op.a, r, T, C, 0);
+        }
+      } else if (op.op == OP_QUIRK) {
+        for (int i = op.a; i < op.a + op.b; i++) visit_prim<FEAT>(S, S.quirk_prim[i], r, T, C, 2);
+      } else if (op.op == OP_QGRID) {
+        DIAG_SPAN_BEGIN();
+        quirk_grid_scan<FEAT>(S, op.pad[0] >= 0 ? S.kqgrid : S.qgrids[op.a], r, T, C);
+        DIAG_SPAN_END(4);
+      } else if (op.op == OP_MESH) {
+        if (FEAT == 0 || op.g < 0 || groups_pass<false>(S, op.g, r, T, C)) {
+          if (op.pad[0] >= 0) {
+            const DKAux& A = S.kaux[op.pad[0]];
+            Ray o = to_object(A.xf, r);
+            bvh_walk<true, FEAT>(S, op.a, op.c, r, o, T, C, stack, stride, &A.root, A.frame);
+          } else {
+            Ray o = to_object(S.xf_inv + 12 * op.b, r);
+            bvh_walk<true, FEAT>(S, op.a, op.c, r, o, T, C, stack, stride);
+          }
+        }
+      } else {
+        if (op.pad[0] >= 0) bvh_walk<false, FEAT>(S, op.a, op.c, r, r, T, C, stack, stride, &S.kaux[op.pad[0]].root, S.kaux[op.pad[0]].frame);
+        else bvh_walk<false, FEAT>(S, op.a, op.c, r, r, T, C, stack, stride);
+      }
+      if (T.mode == MODE_SHADOW_ANY && T.shadowed) return;
+    }
+    return;
+  }
+  int pc = 0;
+  const int n = S.n_ops;
+  while (pc < n) {
+    DIAG_LOOP(2);
+    DOp op = S.ops[pc];
+    if (op.op == OP_PRIM) {
+      visit_prim<FEAT>(S, op.a, r, T, C, 0);
+      pc++;
+    } else if (op.op == OP_QUIRK) {
+      for (int i = op.a; i < op.a + op.b; i++) visit_prim<FEAT>(S, S.quirk_prim[i], r, T, C, 2);
+      pc++;
+    } else if (op.op == OP_QGRID) {
+      DIAG_SPAN_BEGIN();
+      quirk_grid_scan<FEAT>(S, S.qgrids[op.a], r, T, C);
+      DIAG_SPAN_END(4);
+      pc++;
+    } else if (op.op == OP_GROUP) {
+      C.group_tests++;
+      pc = group_box_hit(S.group_box + 6 * op.a, r) ? pc + 1 : op.b;
+    } else if (FEAT >= 3 && op.op == OP_CSG) {
+      if (op.g >= 0 && !groups_pass(S, op.g, r, T, C)) pc = op.b + 1;
+      else pc = csg_eval(S, pc, r, T, C);
+    } else if (op.op == OP_MESH) {
+      if (FEAT == 0 || op.g < 0 || groups_pass<(FEAT >= 2)>(S, op.g, r, T, C)) {
+        Ray o = to_object(S.xf_inv + 12 * op.b, r);
+        bvh_walk<true, FEAT>(S, op.a, op.c, r, o, T, C, stack, stride);
+      }
+      pc++;
+    } else {
+      bvh_walk<false, FEAT>(S, op.a, op.c, r, r, T, C, stack, stride);
+      pc++;
+    }
+    if (T.mode == MODE_SHADOW_ANY && T.shadowed) return;
+  }
+}
+
+// ---- noise (src/noise.rs) ------------------------------------------------------------------------------
+__device__ const unsigned char PERM[256] = {
+    151, 160, 137, 91,  90,  15,  131, 13,  201, 95,  96,  53,  194, 233, 7,   225, 140, 36,  103, 30,  69,  142, 8,   99,  37,  240,
+    21,  10,  23,  190, 6,   148, 247, 120, 234, 75,  0,   26,  197, 62,  94,  252, 219, 203, 117, 35,  11,  32,  57,  177, 33,  88,
+    237, 149, 56,  87,  174, 20,  125, 136, 171, 168, 68,  175, 74,  165, 71,  134, 139, 48,  27,  166, 77,  146, 158, 231, 83,  111,
+    229, 122, 60,  211, 133, 230, 220, 105, 92,  41,  55,  46,  245, 40,  244, 102, 143, 54,  65,  25,  63,  161, 1,   216, 80,  73,
+    209, 76,  132, 187, 208, 89,  18,  169, 200, 196, 135, 130, 116, 188, 159, 86,  164, 100, 109, 198, 173, 186, 3,   64,  52,  217,
+    226, 250, 124, 123, 5,   202, 38,  147, 118, 126, 255, 82,  85,  212, 207, 206, 59,  227, 47,  16,  58,  17,  182, 189, 28,  42,
+    223, 183, 170, 213, 119, 248, 152, 2,   44,  154, 163, 70,  221, 153, 101, 155, 167, 43,  172, 9,   129, 22,  39,  253, 19,  98,
+    108, 110, 79,  113, 224, 232, 178, 185, 112, 104, 218, 246, 97,  228, 251, 34,  242, 193, 238, 210, 144, 12,  191, 179, 162, 241,
+    81,  51,  145, 235, 249, 14,  239, 107, 49,  192, 214, 31,  181, 199, 106, 157, 184, 84,  204, 176, 115, 121, 50,  45,  127, 4,
+    150, 254, 138, 236, 205, 93,  222, 114, 67,  29,  24,  72,  243, 141, 128, 195, 78,  66,  215, 61,  156, 180};
+
+__device__ __forceinline__ unsigned nhash(unsigned i) { return PERM[i & 255u]; }  // :90-92, table period 256
+
+__device__ __forceinline__ int as_i32(double x) {  // Rust `as i32`: saturating, NaN -> 0
+  if (x != x) return 0;
+  if (x >= 2147483647.0) return 2147483647;
+  if (x <= -2147483648.0) return (int)0x80000000;
+  return (int)x;
+}
+__device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+__device__ __forceinline__ int fast_floor(double x) { return x > 0.0 ? as_i32(x) : (int)((unsigned)as_i32(x) - 1u); }  // :116-122
+__device__ __forceinline__ unsigned modulus256(int x) { int a = x % 256; return a < 0 ? (unsigned)(a + 256) : (unsigned)a; }  // :124-131
+
+__device__ __forceinline__ double ngrad(unsigned h, double x, double y, double z) {  // :94-114
+  switch (h & 0xF) {
+    case 0x0: return x + y;
+    case 0x1: return -x + y;
+    case 0x2: return x - y;
+    case 0x3: return -x - y;
+    case 0x4: return x + z;
+    case 0x5: return -x + z;
+    case 0x6: return x - z;
+    case 0x7: return -x - z;
+    case 0x8: return y + z;
+    case 0x9: return -y + z;
+    case 0xA: return y - z;
+    case 0xB: return -y - z;
+    case 0xC: return y + x;
+    case 0xD: return -y + z;
+    case 0xE: return y - x;
+    default: return -y - z;
+  }
+}
+
+__device__ __noinline__ double simplex3(double x, double y, double z) {  // :134-219
+  const double F3 = 1.0 / 3.0, G3 = 1.0 / 6.0;
+  double s = (x + y + z) * F3;
+  int i = fast_floor(x + s), j = fast_floor(y + s), k = fast_floor(z + s);
+  double t = (double)wadd(wadd(i, j), k) * G3;
+  double x0 = x - ((double)i - t), y0 = y - ((double)j - t), z0 = z - ((double)k - t);
+  int i1, j1, k1, i2, j2, k2;
+  if (x0 >= y0) {
+    if (y0 >= z0) { i1 = 1; j1 = 0; k1 = 0; i2 = 1; j2 = 1; k2 = 0; }
+    else if (x0 >= z0) { i1 = 1; j1 = 0; k1 = 0; i2 = 1; j2 = 0; k2 = 1; }
+    else { i1 = 0; j1 = 0; k1 = 1; i2 = 1; j2 = 0; k2 = 1; }
+  } else {
+    if (y0 < z0) { i1 = 0; j1 = 0; k1 = 1; i2 = 0; j2 = 1; k2 = 1; }
+    else if (x0 < z0) { i1 = 0; j1 = 1; k1 = 0; i2 = 0; j2 = 1; k2 = 1; }
+    else { i1 = 0; j1 = 1; k1 = 0; i2 = 1; j2 = 1; k2 = 0; }
+  }
+  double x1 = x0 - (double)i1 + G3, y1 = y0 - (double)j1 + G3, z1 = z0 - (double)k1 + G3;
+  double x2 = x0 - (double)i2 + 2.0 * G3, y2 = y0 - (double)j2 + 2.0 * G3, z2 = z0 - (double)k2 + 2.0 * G3;
+  double x3 = x0 - 1.0 + 3.0 * G3, y3 = y0 - 1.0 + 3.0 * G3, z3 = z0 - 1.0 + 3.0 * G3;
+  unsigned ii = modulus256(i), jj = modulus256(j), kk = modulus256(k);
+  unsigned gi0 = nhash(ii + nhash(jj + nhash(kk)));
+  unsigned gi1 = nhash(ii + i1 + nhash(jj + j1 + nhash(kk + k1)));
+  unsigned gi2 = nhash(ii + i2 + nhash(jj + j2 + nhash(kk + k2)));
+  unsigned gi3 = nhash(ii + 1 + nhash(jj + 1 + nhash(kk + 1)));
+  double n0, n1, n2, n3;
+  double t0 = 0.6 - x0 * x0 - y0 * y0 - z0 * z0;
+  if (t0 < 0.0) n0 = 0.0; else { t0 *= t0; n0 = t0 * t0 * ngrad(gi0, x0, y0, z0); }
+  double t1 = 0.6 - x1 * x1 - y1 * y1 - z1 * z1;
+  if (t1 < 0.0) n1 = 0.0; else { t1 *= t1; n1 = t1 * t1 * ngrad(gi1, x1, y1, z1); }
+  double t2 = 0.6 - x2 * x2 - y2 * y2 - z2 * z2;
+  if (t2 < 0.0) n2 = 0.0; else { t2 *= t2; n2 = t2 * t2 * ngrad(gi2, x2, y2, z2); }
+  double t3 = 0.6 - x3 * x3 - y3 * y3 - z3 * z3;
+  if (t3 < 0.0) n3 = 0.0; else { t3 *= t3; n3 = t3 * t3 * ngrad(gi3, x3, y3, z3); }
+  return 32.0 * (n0 + n1 + n2 + n3);
+}
+
+__device__ __forceinline__ double fractal3(double x, double y, double z, unsigned octaves) {  // :221-237
+  double output = 0.0, denom = 0.0, frequency = 1.0, amplitude = 1.0;
+  for (unsigned o = 0; o < octaves; o++) {
+    output += amplitude * simplex3(x * frequency, y * frequency, z * frequency);
+    denom += amplitude;
+    frequency *= 2.0;
+    amplitude *= 0.5;
+  }
+  return output / denom;
+}
+
+__device__ __forceinline__ void jitter_3d(const DPat& p, double x, double y, double z, double& ox, double& oy, double& oz) {  // :31-52
+  double nx, ny, nz;
+  if (p.noise_kind == 0) {
+    nx = simplex3(x, y, z) * p.scale;
+    ny = simplex3(x, y, z + 1.0) * p.scale;
+    nz = simplex3(x, y, z + 2.0) * p.scale;
+  } else {
+    nx = fractal3(x, y, z, p.octaves) * p.scale;
+    ny = fractal3(x, y, z + 1.0, p.octaves) * p.scale;
+    nz = fractal3(x, y, z + 2.0, p.octaves) * p.scale;
+  }
+  ox = x + nx; oy = y + ny; oz = z + nz;
+}
+
+// ---- Pattern::color_at (src/material.rs:164-302) as an explicit-stack walk of the node array ------------
+struct PFrame {
+  int node, stage;
+  double px, py, pz, pw, frac;
+  double lr, lg, lb;
+};
+
+__device__ __noinline__ void pattern_color(const DScene& S, int root, double px, double py, double pz, double pw, double& r, double& g, double& b) {
+  PFrame fr[8];  // RTC_MAX_PATTERN_DEPTH, validated at scene creation
+  int sp = 0;
+  int node = root;
+  for (;;) {
+    // ---- descend until a colour is known
+    for (;;) {
+      const DPat& p = S.pats[node];
+      if (p.tag == 0) { r = px; g = py; b = pz; break; }
+      if (p.tag == 1) { r = p.color[0]; g = p.color[1]; b = p.color[2]; break; }
+      if (p.tag == 2) {
+        if (p.kind == 1) {  // JitterKind::Point :218-221
+          double nx, ny, nz;
+          jitter_3d(p, px, py, pz, nx, ny, nz);
+          px = nx; py = ny; pz = nz; pw = 1.0;
+          node = p.left;
+        } else {  // JitterKind::Color :209-217
+          fr[sp].node = node; fr[sp].stage = 2; sp++;
+          node = p.left;
+        }
+        continue;
+      }
+      // Mixture: point = transform_inv * point (:181-183)
+      {
+        const double* m = p.m;
+        double x = m[0] * px + m[1] * py + m[2] * pz + m[3] * pw;
+        double y = m[4] * px + m[5] * py + m[6] * pz + m[7] * pw;
+        double z = m[8] * px + m[9] * py + m[10] * pz + m[11] * pw;
+        double w = m[12] * px + m[13] * py + m[14] * pz + m[15] * pw;
+        px = x; py = y; pz = z; pw = w;
+      }
+      if (p.kind == 1) {  // Checkers :258-268
+        int xi = as_i32(floor(px)), yi = as_i32(floor(py)), zi = as_i32(floor(pz));
+        node = (wadd(wadd(xi, yi), zi) % 2 == 0) ? p.left : p.right;
+      } else if (p.kind == 3) {  // Ring :278-284
+        node = (as_i32(floor(sqrt(px * px + pz * pz))) % 2 == 0) ? p.left : p.right;
+      } else if (p.kind == 5) {  // Stripes :293-299
+        node = (as_i32(floor(px)) % 2 == 0) ? p.left : p.right;
+      } else {  // Blend / RingGradient / Gradient: both children
+        double frac = 0.0;
+        if (p.kind == 2) { double d = sqrt(px * px + py * py + pz * pz); frac = d - floor(d); }  // :269-277
+        else if (p.kind == 4) frac = px - floor(px);                                             // :285-292
+        fr[sp].node = node; fr[sp].stage = 0; fr[sp].px = px; fr[sp].py = py; fr[sp].pz = pz; fr[sp].pw = pw; fr[sp].frac = frac;
+        sp++;
+        node = p.left;
+      }
+    }
+    // ---- ascend
+    bool again = false;
+    while (sp > 0) {
+      PFrame& f = fr[sp - 1];
+      const DPat& p = S.pats[f.node];
+      if (f.stage == 2) {
+        double nr, ng, nb;
+        jitter_3d(p, r, g, b, nr, ng, nb);
+        r = nr; g = ng; b = nb;
+        sp--;
+      } else if (f.stage == 0) {
+        f.lr = r; f.lg = g; f.lb = b; f.stage = 1;
+        px = f.px; py = f.py; pz = f.pz; pw = f.pw;
+        node = p.right;
+        again = true;
+        break;
+      } else {
+        if (p.kind == 0) { r = (f.lr + r) * 0.5; g = (f.lg + g) * 0.5; b = (f.lb + b) * 0.5; }  // Color::avg
+        else { r = f.lr + ((r - f.lr) * f.frac); g = f.lg + ((g - f.lg) * f.frac); b = f.lb + ((b - f.lb) * f.frac); }
+        sp--;
+      }
+    }
+    if (!again) return;
+  }
+}
+
+// ---- hit state (Intersection::prepare_state, src/intersection.rs:50-121) --------------------------------
+struct State {
+  double px, py, pz;     // over_point
+  double ux, uy, uz;     // under_point
+  double nx, ny, nz;     // normal (flipped when inside)
+  double ex, ey, ez;     // eye
+  double rx, ry, rz;     // reflect
+};
+
+// Geometry::normal (src/shape.rs:887-946) in object space
+__device__ __forceinline__ void local_normal(const DScene& S, const DPrim& P, double x, double y, double z, double u, double v, double& nx, double& ny, double& nz) {
+  switch (P.geom) {
+    case 0: nx = x; ny = y; nz = z; return;
+    case 1: nx = 0.0; ny = 1.0; nz = 0.0; return;
+    case 2: {
+      double xa = fabs(x), ya = fabs(y), za = fabs(z);
+      double mx = rmax(rmax(xa, ya), za);
+      if (mx == xa) { nx = x; ny = 0.0; nz = 0.0; }
+      else if (mx == ya) { nx = 0.0; ny = y; nz = 0.0; }
+      else { nx = 0.0; ny = 0.0; nz = z; }
+      return;
+    }
+    case 3:
+    case 4: {
+      double mn = S.limits[2 * P.data], mxl = S.limits[2 * P.data + 1];
+      double dist = x * x + z * z;
+      if (dist < 1.0 && y >= mxl - EPS) { nx = 0.0; ny = 1.0; nz = 0.0; return; }
+      if (dist < 1.0 && y <= mn + EPS) { nx = 0.0; ny = -1.0; nz = 0.0; return; }
+      if (P.geom == 3) { nx = x; ny = 0.0; nz = z; return; }
+      double yy = sqrt(dist);
+      if (y > 0.0) yy = -yy;
+      nx = x; ny = yy; nz = z;
+      return;
+    }
+    case 5: {
+      const double* n = S.tri_nrm + 9 * P.data;
+      nx = n[0]; ny = n[1]; nz = n[2];
+      return;
+    }
+    default: {  // *n2 * u + *n3 * v + *n1 * (1.0 - u - v)
+      const double* n = S.tri_nrm + 9 * P.data;
+      double w = 1.0 - u - v;
+      nx = n[3] * u + n[6] * v + n[0] * w;
+      ny = n[4] * u + n[7] * v + n[1] * w;
+      nz = n[5] * u + n[8] * v + n[2] * w;
+      return;
+    }
+  }
+}
+
+__device__ __forceinline__ void prepare_state(const DScene& S, const DPrim& P, const Ray& r, double t, double u, double v, State& st) {
+  // point = ray.position(t); eye = -direction
+  double qx = r.ox + r.dx * t, qy = r.oy + r.dy * t, qz = r.oz + r.dz * t;
+  st.ex = -r.dx; st.ey = -r.dy; st.ez = -r.dz;
+  // Shape::normal (src/shape.rs:419-427)
+  const double* m = S.xf_inv + 12 * P.xform;
+  double sx = m[0] * qx + m[1] * qy + m[2] * qz + m[3] * 1.0;
+  double sy = m[4] * qx + m[5] * qy + m[6] * qz + m[7] * 1.0;
+  double sz = m[8] * qx + m[9] * qy + m[10] * qz + m[11] * 1.0;
+  double lx, ly, lz;
+  local_normal(S, P, sx, sy, sz, u, v, lx, ly, lz);
+  // transform_inv_tsp * n: row r of the transpose = column r of transform_inv; the w term is (+-0)*0
+  double wx = m[0] * lx + m[4] * ly + m[8] * lz + 0.0;
+  double wy = m[1] * lx + m[5] * ly + m[9] * lz + 0.0;
+  double wz = m[2] * lx + m[6] * ly + m[10] * lz + 0.0;
+  double mag = sqrt(wx * wx + wy * wy + wz * wz);
+  double nx = wx / mag, ny = wy / mag, nz = wz / mag;
+  if (nx * st.ex + ny * st.ey + nz * st.ez < 0.0) { nx = -nx; ny = -ny; nz = -nz; }
+  st.nx = nx; st.ny = ny; st.nz = nz;
+  st.px = qx + nx * EPS; st.py = qy + ny * EPS; st.pz = qz + nz * EPS;
+  st.ux = qx - nx * EPS; st.uy = qy - ny * EPS; st.uz = qz - nz * EPS;
+  // reflect = direction - normal * (2 * direction.dot(normal))
+  double dn = 2.0 * (r.dx * nx + r.dy * ny + r.dz * nz);
+  st.rx = r.dx - nx * dn; st.ry = r.dy - ny * dn; st.rz = r.dz - nz * dn;
+}
+
+// schlick (src/intersection.rs:24-39)
+__device__ __forceinline__ double schlick(const State& st, double n1, double n2) {
+  double c = st.ex * st.nx + st.ey * st.ny + st.ez * st.nz;
+  if (n1 > n2) {
+    double n = n1 / n2;
+    double sin2_t = n * n * (1.0 - c * c);
+    if (sin2_t > 1.0) return 1.0;
+    c = sqrt(1.0 - sin2_t);
+  }
+  double q = (n1 - n2) / (n1 + n2);
+  double r0 = q * q;
+  double x = 1.0 - c;
+  double x5 = x * ((x * x) * (x * x));
+  return r0 + (1.0 - r0) * x5;
+}
+
+__device__ __forceinline__ void reset_closest(Trav& T, int mode) {
+  T.mode = mode;
+  T.tlo = 0.0; T.thi = DINF;
+  T.best_t = DINF; T.best_prim = 0x7fffffff; T.best_k = 0; T.best_klast = 0;
+  T.shadowed = 0;
+  T.unordered = 0;
+  T.c1_t = 0.0; T.c2_t = 0.0; T.c1_prim = -1; T.c2_prim = -1;
+  T.g_known = 0ull; T.g_pass = 0ull;
+}
+
+// u, v of the winning triangle: the traversal does not carry them; the same test on the same numbers gives the same bits.
+__device__ __forceinline__ void hit_uv(const DScene& S, const DPrim& P, const Ray& world, double& u, double& v) {
+  u = 0.0; v = 0.0;
+  if (P.geom >= 5) {
+    Ray o = to_object(S.xf_inv + 12 * P.xform, world);
+    double t;
+    tri_hit(S.tri_geo + 9 * P.data, o, t, u, v);
+  }
+}
+
+struct Pending {
+  double ox, oy, oz, dx, dy, dz, weight;
+  int fuel, kind;
+};
+
+// Camera::ray_at_pixel (src/camera.rs:39-55)
+__device__ __forceinline__ Ray camera_ray(const DCamera& cam, uint64_t i) {
+  uint64_t x = i % cam.hsize, y = i / cam.hsize;
+  double xoffset = ((double)x + 0.5) * cam.pixel_size;
+  double yoffset = ((double)y + 0.5) * cam.pixel_size;
+  double world_x = cam.half_width - xoffset;
+  double world_y = cam.half_height - yoffset;
+  const double* m = cam.inv;
+  double px = m[0] * world_x + m[1] * world_y + m[2] * -1.0 + m[3] * 1.0;
+  double py = m[4] * world_x + m[5] * world_y + m[6] * -1.0 + m[7] * 1.0;
+  double pz = m[8] * world_x + m[9] * world_y + m[10] * -1.0 + m[11] * 1.0;
+  Ray r;
+  r.ox = m[3]; r.oy = m[7]; r.oz = m[11];
+  double dx = px - r.ox, dy = py - r.oy, dz = pz - r.oz;
+  double mag = sqrt(dx * dx + dy * dy + dz * dz);
+  r.dx = dx / mag; r.dy = dy / mag; r.dz = dz / mag;
+  return r;
+}
+
+
+
+// Pixel slots.  A launch covers `pm.n` output slots.  With tiling (full-width pixel sets: mode 0 with whole rows, mode 2) the
+// work items are enumerated tile by tile (8x8 pixels, 64 consecutive work ids = one tile) so that the lanes of a wave,
+// and the pixels a lane fetches later, stay spatially close; a work id that falls outside the image is skipped.
+struct WorkMap {
+  uint64_t n_work;      // number of work ids
+  uint32_t tiled, tiles_x, width, height;
+};
+__device__ __forceinline__ WorkMap make_workmap(const DPixelMap& pm, const DCamera& cam) {
+  WorkMap w;
+  w.tiled = 0; w.tiles_x = 0; w.width = 0; w.height = 0; w.n_work = pm.n;
+  if (pm.mode == 2 && cam.hsize >= 8 && pm.n % cam.hsize == 0) {
+    w.tiled = 1;
+    w.width = (uint32_t)cam.hsize;
+    w.height = (uint32_t)(pm.n / cam.hsize);
+    w.tiles_x = (w.width + 7u) / 8u;
+    w.n_work = (uint64_t)w.tiles_x * ((w.height + 7u) / 8u) * 64u;
+  }
+  return w;
+}
+// work id -> output slot q (row-major within the launch's pixel set); false if the id is padding.
+__device__ __forceinline__ bool work_to_slot(const WorkMap& w, uint64_t id, uint64_t& q) {
+  if (!w.tiled) { q = id; return true; }
+  uint64_t tile = id >> 6;
+  uint32_t in = (uint32_t)(id & 63u);
+  uint32_t x = (uint32_t)(tile % w.tiles_x) * 8u + (in & 7u), y = (uint32_t)(tile / w.tiles_x) * 8u + (in >> 3);
+  if (x >= w.width || y >= w.height) return false;
+  q = (uint64_t)y * w.width + x;
+  return true;
+}
+__device__ __forceinline__ Ray slot_ray(const DPixelMap& pm, const DCamera& cam, uint64_t q) {
+  if (pm.mode == 3) {
+    const double* rr = pm.rays + 6 * q;
+    Ray r;
+    r.ox = rr[0]; r.oy = rr[1]; r.oz = rr[2]; r.dx = rr[3]; r.dy = rr[4]; r.dz = rr[5];
+    return r;
+  }
+  // the host only issues modes 1 (index list), 2 (interleaved rows; a contiguous whole-row range is step 1) and 3 (rays)
+  uint64_t i;
+  if (pm.mode == 1) i = pm.indices[q];
+  else i = ((uint64_t)pm.row_first + (q / cam.hsize) * pm.row_step) * cam.hsize + (q % cam.hsize);
+  return camera_ray(cam, i);
+}
+
+}  // namespace
+
+// One-kernel path: one lane walks one pixel's whole ray tree (closest pass, shading, shadow passes, pending children); the wave
+// ends with its slowest pixel.  (A persistent variant whose lanes took the next work id from a global counter was measured at
+// -4 % / +14 % and removed in round 2.)
+template <bool COUNT, int FEAT>
+__global__ void __launch_bounds__(RTC_BLOCK, (FEAT >= 2 && RTC_WAVES_PER_SIMD < 2) ? 2 : RTC_WAVES_PER_SIMD) rtc_trace_kernel(DScene S, DCamera cam, DPixelMap pm, int fuel0, double* __restrict__ rgb, double* __restrict__ hit_t,
+                                                        int* __restrict__ hit_prim, int* __restrict__ hit_k, DStats* __restrict__ stats) {
+  RTC_LDS_STACK(lds_stack);
+  int* stack = lds_stack + threadIdx.x;
+  const int stride = RTC_BLOCK;
+  Counters C = {0, 0, 0, 0, 0, 0, 0};
+  unsigned n_primary = 0, n_shadow = 0, n_reflect = 0, n_refract = 0, n_container = 0;
+  const WorkMap wm = make_workmap(pm, cam);
+#ifdef RTC_DIAG
+  if (threadIdx.x < 32) s_diag[threadIdx.x] = 0ull;
+  __syncthreads();
+  unsigned long long diag_t0_ = 0;
+  const unsigned long long diag_k0 = __builtin_amdgcn_s_memtime();
+#endif
+
+  const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t q = 0;
+  const bool have = id < wm.n_work && work_to_slot(wm, id, q);
+
+  if (have) {
+    Ray ray = slot_ray(pm, cam, q);
+
+    Pending pend[RTC_MAX_FUEL];
+    int np = 0;
+    double acc_r = 0.0, acc_g = 0.0, acc_b = 0.0;
+    double weight = 1.0;
+    int fuel = fuel0;
+    int kind = 0;
+    bool first = true;
+    const double L = (double)S.n_lights;
+
+    for (;;) {
+      if (kind == 0) n_primary++; else if (kind == 1) n_reflect++; else n_refract++;
+      DIAG_LOOP(4);
+      DIAG_T0();
+      Trav T;
+      reset_closest(T, MODE_CLOSEST);
+      traverse<FEAT>(S, ray, T, C, stack, stride);
+      DIAG_REGION(0);
+      bool did_hit = T.best_prim != 0x7fffffff;
+      if (first) {
+        first = false;
+        if (hit_t) {
+          hit_t[q] = did_hit ? T.best_t : 0.0;
+          hit_prim[q] = did_hit ? T.best_prim : -1;
+          hit_k[q] = did_hit ? T.best_k : 0;
+        }
+      }
+      if (did_hit) {
+        const DPrim P = S.prims[T.best_prim];
+        const double* M = S.mat + 8 * P.mat;
+        const double ambient = M[0], diffuse = M[1], specular = M[2], shininess = M[3], reflective = M[4], transparency = M[5];
+        State st;
+        double hu, hv;
+        hit_uv(S, P, ray, hu, hv);
+        prepare_state(S, P, ray, T.best_t, hu, hv, st);
+
+        // n1 / n2 / reflectance are only consumed when the surface is transparent (src/world.rs:70-78, :110)
+        double n1 = 1.0, n2 = 1.0;
+        if (transparency != 0.0) {
+          n_container++;
+          Trav K = T;  // keeps the hit key (thi = best_t, best_prim, best_klast)
+          K.mode = MODE_CONTAINERS;
+          K.tlo = -DINF; K.thi = T.best_t;
+          K.c1_prim = -1; K.c2_prim = -1; K.c1_t = 0.0; K.c2_t = 0.0;
+          traverse<FEAT>(S, ray, K, C, stack, stride);
+          if (K.c1_prim >= 0) n1 = S.mat[8 * S.prims[K.c1_prim].mat + 6];
+          if (K.c2_prim >= 0) n2 = S.mat[8 * S.prims[K.c2_prim].mat + 6];
+          DIAG_REGION(1);
+        }
+
+        // Pattern::color_at(material_inv * over_point) — identical for every light (src/shape.rs:437)
+        double cr, cg, cb;
+        {
+          const double* mi = S.xf_matinv + 16 * P.xform;
+          double x = mi[0] * st.px + mi[1] * st.py + mi[2] * st.pz + mi[3] * 1.0;
+          double y = mi[4] * st.px + mi[5] * st.py + mi[6] * st.pz + mi[7] * 1.0;
+          double z = mi[8] * st.px + mi[9] * st.py + mi[10] * st.pz + mi[11] * 1.0;
+          double w = mi[12] * st.px + mi[13] * st.py + mi[14] * st.pz + mi[15] * 1.0;
+          const DPat& root = S.pats[S.mat_pattern[P.mat]];
+          if (root.tag == 1) { cr = root.color[0]; cg = root.color[1]; cb = root.color[2]; }
+          else pattern_color(S, S.mat_pattern[P.mat], x, y, z, w, cr, cg, cb);
+        }
+
+        DIAG_REGION(2);
+        // World::shade_hit (src/world.rs:50-82): per light, shadow test + Phong (src/shape.rs:429-462)
+        double sr = 0.0, sg = 0.0, sb = 0.0;
+        for (int l = 0; l < S.n_lights; l++) {
+          DIAG_LOOP(5);
+          const double* LG = S.lights + 6 * l;
+          double vx = LG[3] - st.px, vy = LG[4] - st.py, vz = LG[5] - st.pz;
+          double distance = sqrt(vx * vx + vy * vy + vz * vz);
+          Ray sray;
+          sray.ox = st.px; sray.oy = st.py; sray.oz = st.pz;
+          sray.dx = vx / distance; sray.dy = vy / distance; sray.dz = vz / distance;
+          n_shadow++;
+          Trav Sh;
+          reset_closest(Sh, S.all_cast_shadow ? MODE_SHADOW_ANY : MODE_SHADOW_CLOSEST);
+          if (S.all_cast_shadow) Sh.thi = distance;
+          DIAG_T0();
+          traverse<FEAT>(S, sray, Sh, C, stack, stride);
+          DIAG_REGION(3);
+          bool shadowed;
+          if (S.all_cast_shadow) shadowed = Sh.shadowed != 0;
+          else shadowed = (Sh.best_prim != 0x7fffffff) && (S.prims[Sh.best_prim].flags & 1u) && (Sh.best_t < distance);
+
+          double er = cr * LG[0], eg = cg * LG[1], eb = cb * LG[2];  // effective_color
+          double lr = er * ambient, lg = eg * ambient, lb = eb * ambient;
+          // light vector: (light.origin - point).normalize() — same numbers as the shadow ray direction
+          double ldn = sray.dx * st.nx + sray.dy * st.ny + sray.dz * st.nz;
+          double dr = 0.0, dg = 0.0, db = 0.0, pr = 0.0, pg = 0.0, pb = 0.0;
+          if (!shadowed && ldn >= 0.0) {
+            dr = er * diffuse * ldn; dg = eg * diffuse * ldn; db = eb * diffuse * ldn;
+            // reflect = (-light).reflect(normal)
+            double mlx = -sray.dx, mly = -sray.dy, mlz = -sray.dz;
+            double d2 = 2.0 * (mlx * st.nx + mly * st.ny + mlz * st.nz);
+            double rfx = mlx - st.nx * d2, rfy = mly - st.ny * d2, rfz = mlz - st.nz * d2;
+            double rde = rfx * st.ex + rfy * st.ey + rfz * st.ez;
+            if (rde > 0.0) {
+              double f = pow(rde, shininess);
+              pr = LG[0] * specular * f; pg = LG[1] * specular * f; pb = LG[2] * specular * f;
+            }
+          }
+          sr += (lr + dr) + pr; sg += (lg + dg) + pg; sb += (lb + db) + pb;
+        }
+        acc_r += weight * sr; acc_g += weight * sg; acc_b += weight * sb;
+        DIAG_T0();
+
+        // reflected_color / refracted_color (src/world.rs:84-132), once per light in the reference -> factor L
+        if (fuel > 0) {
+          bool do_refl = reflective != 0.0;
+          bool do_refr = transparency != 0.0;
+          double wr = weight * L * reflective, wt = weight * L * transparency;
+          if (reflective > 0.0 && transparency > 0.0) {
+            double R = schlick(st, n1, n2);
+            wr *= R;
+            wt *= (1.0 - R);
+          }
+          double tdx = 0.0, tdy = 0.0, tdz = 0.0;
+          if (do_refr) {
+            double n_ratio = n1 / n2;
+            double cos_i = st.ex * st.nx + st.ey * st.ny + st.ez * st.nz;
+            double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
+            if (sin2_t > 1.0) do_refr = false;
+            else {
+              double cos_t = sqrt(1.0 - sin2_t);
+              double kk = n_ratio * cos_i - cos_t;
+              tdx = st.nx * kk - st.ex * n_ratio; tdy = st.ny * kk - st.ey * n_ratio; tdz = st.nz * kk - st.ez * n_ratio;
+            }
+          }
+          // depth-first: the reflection ray (if any) is traced next; only a refraction ray that has to wait is stacked
+          if (do_refr && do_refl) {
+            Pending& p = pend[np++];
+            p.ox = st.ux; p.oy = st.uy; p.oz = st.uz; p.dx = tdx; p.dy = tdy; p.dz = tdz;
+            p.weight = wt; p.fuel = fuel - 1; p.kind = 2;
+          }
+          if (do_refl) {
+            ray.ox = st.px; ray.oy = st.py; ray.oz = st.pz; ray.dx = st.rx; ray.dy = st.ry; ray.dz = st.rz;
+            weight = wr; fuel = fuel - 1; kind = 1;
+            continue;
+          }
+          if (do_refr) {
+            ray.ox = st.ux; ray.oy = st.uy; ray.oz = st.uz; ray.dx = tdx; ray.dy = tdy; ray.dz = tdz;
+            weight = wt; fuel = fuel - 1; kind = 2;
+            continue;
+          }
+        }
+      }
+      DIAG_REGION(5);
+      if (np == 0) {
+        rgb[3 * q + 0] = acc_r;
+        rgb[3 * q + 1] = acc_g;
+        rgb[3 * q + 2] = acc_b;
+        break;
+      }
+      const Pending& p = pend[--np];
+      ray.ox = p.ox; ray.oy = p.oy; ray.oz = p.oz; ray.dx = p.dx; ray.dy = p.dy; ray.dz = p.dz;
+      weight = p.weight; fuel = p.fuel; kind = p.kind;
+    }
+  }
+
+#ifdef RTC_DIAG
+  atomicAdd(&s_diag[14], __builtin_amdgcn_s_memtime() - diag_k0);
+  atomicAdd(&s_diag[15], 1ull);
+  __syncthreads();
+  if (threadIdx.x < 32 && s_diag[threadIdx.x]) atomicAdd(&stats->diag[threadIdx.x], s_diag[threadIdx.x]);
+#endif
+  if (COUNT || true) {
+    // nan_ts must always be published (error reporting); the rest only in the counting variant
+    if (C.nan_ts) atomicAdd(&stats->nan_ts, (unsigned long long)C.nan_ts);
+  }
+  if (COUNT) {
+    atomicAdd(&stats->rays_primary, (unsigned long long)n_primary);
+    atomicAdd(&stats->rays_shadow, (unsigned long long)n_shadow);
+    atomicAdd(&stats->rays_reflect, (unsigned long long)n_reflect);
+    atomicAdd(&stats->rays_refract, (unsigned long long)n_refract);
+    atomicAdd(&stats->rays_container, (unsigned long long)n_container);
+    atomicAdd(&stats->accel_nodes, (unsigned long long)C.accel_nodes);
+    atomicAdd(&stats->group_tests, (unsigned long long)C.group_tests);
+    atomicAdd(&stats->tri_tests, (unsigned long long)C.tri_tests);
+    atomicAdd(&stats->analytic_tests, (unsigned long long)C.analytic_tests);
+    atomicAdd(&stats->knodes, (unsigned long long)C.knodes);
+    atomicAdd(&stats->kplanes, (unsigned long long)C.kplanes);
+  }
+}
+
+// =================================================================================================================
+// Wavefront path (DWave in device_scene.h): the same device functions as rtc_trace_kernel, cut into per-level kernels.
+//   wf_ts      trace role: closest hit (+ container pass for transparent hits) of every ray of level d;
+//              shadow role: per shade record of level d - 1 and light, shadow ray + Phong terms -> the ray's colour contribution
+//   wf_shade   hit state, pattern colour -> shade record; reflected / refracted rays -> the other queue
+//   wf_gather  pixel = its ray tree's contributions, added in the one-kernel path's order (bit-identical results)
+// Every kernel loops over counts that live in device memory, so a frame is enqueued without host syncs.
+// =================================================================================================================
+namespace {
+
+__device__ __forceinline__ unsigned wf_count(const DWave& W, int level, unsigned n0) {
+  if (level == 0) return n0;
+  unsigned c = W.counts[level];
+  return c < W.cap ? c : W.cap;
+}
+__device__ __forceinline__ Ray wf_load_ray(const DWave& W, int level, unsigned i, double& weight) {
+  const double* q = W.rq[level & 1];
+  const size_t cap = W.cap;
+  Ray r;
+  r.ox = q[i]; r.oy = q[cap + i]; r.oz = q[2 * cap + i]; r.dx = q[3 * cap + i]; r.dy = q[4 * cap + i]; r.dz = q[5 * cap + i];
+  weight = q[6 * cap + i];
+  return r;
+}
+
+}  // namespace
+
+// wf_ts work item of the trace role: ray i of `level` (closest hit, container pass for transparent hits).
+template <int FEAT>
+__device__ __forceinline__ void wf_trace_ray(const DScene& S, const DCamera& cam, const DPixelMap& pm, const DWave& W, const WorkMap& wm, int level, unsigned i,
+                                             double* __restrict__ hit_t, int* __restrict__ hit_prim, int* __restrict__ hit_k, int* stack, int stride, Counters& C,
+                                             unsigned& n_rays, unsigned& n_container) {
+  const size_t cap = W.cap;
+  double* cb = W.contrib + (size_t)level * 3 * cap;
+  int32_t* ch = W.child + (size_t)level * 2 * cap;
+  cb[i] = 0.0; cb[cap + i] = 0.0; cb[2 * cap + i] = 0.0;
+  ch[i] = -1; ch[cap + i] = -1;
+  Ray ray;
+  uint64_t q = 0;
+  if (level == 0) {
+    if (!work_to_slot(wm, i, q)) { W.h_prim[i] = -1; return; }
+    ray = slot_ray(pm, cam, q);
+  } else {
+    double w_;
+    ray = wf_load_ray(W, level, i, w_);
+  }
+  n_rays++;
+  Trav T;
+  reset_closest(T, MODE_CLOSEST);
+  traverse<FEAT>(S, ray, T, C, stack, stride);
+  const bool did_hit = T.best_prim != 0x7fffffff;
+  if (level == 0 && hit_t) {
+    hit_t[q] = did_hit ? T.best_t : 0.0;
+    hit_prim[q] = did_hit ? T.best_prim : -1;
+    hit_k[q] = did_hit ? T.best_k : 0;
+  }
+  W.h_prim[i] = did_hit ? T.best_prim : -1;
+  if (!did_hit) return;
+  W.h_t[i] = T.best_t;
+  // n1 / n2 are only consumed when the surface is transparent (src/world.rs:70-78, :110)
+  double n1 = 1.0, n2 = 1.0;
+  if (S.mat[8 * S.prims[T.best_prim].mat + 5] != 0.0) {
+    n_container++;
+    Trav K = T;  // keeps the hit key (thi = best_t, best_prim, best_klast)
+    K.mode = MODE_CONTAINERS;
+    K.tlo = -DINF; K.thi = T.best_t;
+    K.c1_prim = -1; K.c2_prim = -1; K.c1_t = 0.0; K.c2_t = 0.0;
+    traverse<FEAT>(S, ray, K, C, stack, stride);
+    if (K.c1_prim >= 0) n1 = S.mat[8 * S.prims[K.c1_prim].mat + 6];
+    if (K.c2_prim >= 0) n2 = S.mat[8 * S.prims[K.c2_prim].mat + 6];
+  }
+  W.h_n12[i] = n1; W.h_n12[cap + i] = n2;
+}
+
+// wf_ts work item of the shadow role: shade record s of `level` (per light: shadow ray, then the Phong terms).
+template <int FEAT>
+__device__ __forceinline__ void wf_shadow_rec(const DScene& S, const DWave& W, int level, unsigned s, int* stack, int stride, Counters& C, unsigned& n_shadow) {
+  const size_t cap = W.cap;
+  double* cb = W.contrib + (size_t)level * 3 * cap;
+  const double* r = W.sr[level & 1];
+  const double px = r[s], py = r[cap + s], pz = r[2 * cap + s];
+  // World::shade_hit (src/world.rs:50-82): per light, shadow test + Phong (src/shape.rs:429-462).  First every shadow
+  // ray (only the point is live across the traversals), then the Phong terms with the rest of the record.
+  unsigned long long shadow_mask = 0ull;  // <= 64 lights (checked at scene creation)
+  for (int l = 0; l < S.n_lights; l++) {
+    const double* LG = S.lights + 6 * l;
+    double vx = LG[3] - px, vy = LG[4] - py, vz = LG[5] - pz;
+    double distance = sqrt(vx * vx + vy * vy + vz * vz);
+    Ray sray;
+    sray.ox = px; sray.oy = py; sray.oz = pz;
+    sray.dx = vx / distance; sray.dy = vy / distance; sray.dz = vz / distance;
+    n_shadow++;
+    Trav Sh;
+    reset_closest(Sh, S.all_cast_shadow ? MODE_SHADOW_ANY : MODE_SHADOW_CLOSEST);
+    if (S.all_cast_shadow) { Sh.thi = distance; Sh.unordered = 1; }
+    traverse<FEAT>(S, sray, Sh, C, stack, stride);
+    bool shadowed;
+    if (S.all_cast_shadow) shadowed = Sh.shadowed != 0;
+    else shadowed = (Sh.best_prim != 0x7fffffff) && (S.prims[Sh.best_prim].flags & 1u) && (Sh.best_t < distance);
+    if (shadowed) shadow_mask |= 1ull << l;
+  }
+  const double ex = r[3 * cap + s], ey = r[4 * cap + s], ez = r[5 * cap + s];
+  const double nx = r[6 * cap + s], ny = r[7 * cap + s], nz = r[8 * cap + s];
+  const double cr = r[9 * cap + s], cg = r[10 * cap + s], cbl = r[11 * cap + s];
+  const double* M = S.mat + 8 * W.sr_mat[level & 1][s];
+  const double ambient = M[0], diffuse = M[1], specular = M[2], shininess = M[3];
+  double sr = 0.0, sg = 0.0, sb = 0.0;
+  for (int l = 0; l < S.n_lights; l++) {
+    const double* LG = S.lights + 6 * l;
+    double vx = LG[3] - px, vy = LG[4] - py, vz = LG[5] - pz;
+    double distance = sqrt(vx * vx + vy * vy + vz * vz);
+    const double ldx = vx / distance, ldy = vy / distance, ldz = vz / distance;  // the shadow ray's direction again
+    const bool shadowed = (shadow_mask >> l) & 1ull;
+    double er = cr * LG[0], eg = cg * LG[1], eb = cbl * LG[2];  // effective_color
+    double lr = er * ambient, lg = eg * ambient, lb = eb * ambient;
+    // light vector: (light.origin - point).normalize() — same numbers as the shadow ray direction
+    double ldn = ldx * nx + ldy * ny + ldz * nz;
+    double dr = 0.0, dg = 0.0, db = 0.0, pr = 0.0, pg = 0.0, pb = 0.0;
+    if (!shadowed && ldn >= 0.0) {
+      dr = er * diffuse * ldn; dg = eg * diffuse * ldn; db = eb * diffuse * ldn;
+      // reflect = (-light).reflect(normal)
+      double mlx = -ldx, mly = -ldy, mlz = -ldz;
+      double d2 = 2.0 * (mlx * nx + mly * ny + mlz * nz);
+      double rfx = mlx - nx * d2, rfy = mly - ny * d2, rfz = mlz - nz * d2;
+      double rde = rfx * ex + rfy * ey + rfz * ez;
+      if (rde > 0.0) {
+        double f = pow(rde, shininess);
+        pr = LG[0] * specular * f; pg = LG[1] * specular * f; pb = LG[2] * specular * f;
+      }
+    }
+    sr += (lr + dr) + pr; sg += (lg + dg) + pg; sb += (lb + db) + pb;
+  }
+  const double weight = r[12 * cap + s];
+  const int node = W.sr_node[level & 1][s];
+  cb[node] = weight * sr; cb[cap + node] = weight * sg; cb[2 * cap + node] = weight * sb;
+}
+
+// Traversal kernel of the wavefront path: the closest-hit pass of level `tl` and the shadow + lighting pass of level `sl`
+// (either may be -1) as ONE launch, so the two independent passes fill the chip together.  Work is handed out in chunks of
+// RTC_WF_CHUNK items from per-XCD counters (block b belongs to XCD b % 8 and takes chunks b % 8, b % 8 + 8, ...): trace
+// chunks first (the next shading kernel waits for them), then shadow chunks; a wave that finishes early simply takes more.
+template <bool COUNT, int FEAT>
+__global__ void __launch_bounds__(RTC_BLOCK, FEAT <= 1 ? 4 : 2) wf_ts(DScene S, DCamera cam, DPixelMap pm, DWave W, int tl, int sl, unsigned n0, int slot, double* __restrict__ hit_t,
+                                                                     int* __restrict__ hit_prim, int* __restrict__ hit_k, DStats* __restrict__ stats) {
+  RTC_LDS_STACK(lds_stack);
+  int* stack = lds_stack + threadIdx.x;
+  const int stride = RTC_BLOCK;
+  Counters C = {0, 0, 0, 0, 0, 0, 0};
+  unsigned n_rays = 0, n_container = 0, n_shadow = 0;
+  const WorkMap wm = make_workmap(pm, cam);
+  const unsigned nt = tl >= 0 ? wf_count(W, tl, n0) : 0u;
+  unsigned ns = sl >= 0 ? W.counts[RTC_WF_SHADE_COUNT + sl] : 0u;
+  if (ns > W.cap) ns = W.cap;
+  const unsigned ct = (nt + RTC_WF_CHUNK - 1) / RTC_WF_CHUNK, cs = (ns + RTC_WF_CHUNK - 1) / RTC_WF_CHUNK;
+  const unsigned nx = gridDim.x < 8u ? gridDim.x : 8u;  // chunk residues in use (a grid smaller than 8 blocks has fewer)
+  const unsigned x = blockIdx.x % nx;
+  unsigned* next = &W.counts[RTC_WF_CHUNK_NEXT + 32 * (8 * slot + (int)x)];
+  const int lane = RTC_LANE_ID;
+  for (;;) {
+    unsigned kx = 0;
+    if (lane == 0) kx = atomicAdd(next, 1u);
+    kx = __shfl(kx, 0);
+    const unsigned long long chunk = (unsigned long long)kx * nx + x;
+    if (chunk >= (unsigned long long)ct + cs) break;
+    if (chunk < ct) {
+      const unsigned base = (unsigned)chunk * RTC_WF_CHUNK;
+      for (unsigned o = 0; o < RTC_WF_CHUNK; o += RTC_WF_LANES) {
+        const unsigned i = base + o + (unsigned)lane;
+        if (i < nt) wf_trace_ray<FEAT>(S, cam, pm, W, wm, tl, i, hit_t, hit_prim, hit_k, stack, stride, C, n_rays, n_container);
+      }
+    } else {
+      const unsigned base = (unsigned)(chunk - ct) * RTC_WF_CHUNK;
+      for (unsigned o = 0; o < RTC_WF_CHUNK; o += RTC_WF_LANES) {
+        const unsigned s = base + o + (unsigned)lane;
+        if (s < ns) wf_shadow_rec<FEAT>(S, W, sl, s, stack, stride, C, n_shadow);
+      }
+    }
+  }
+  if (C.nan_ts) atomicAdd(&stats->nan_ts, (unsigned long long)C.nan_ts);
+  if (COUNT) {
+    if (tl == 0) atomicAdd(&stats->rays_primary, (unsigned long long)n_rays);
+    atomicAdd(&stats->rays_container, (unsigned long long)n_container);
+    atomicAdd(&stats->rays_shadow, (unsigned long long)n_shadow);
+    atomicAdd(&stats->accel_nodes, (unsigned long long)C.accel_nodes);
+    atomicAdd(&stats->group_tests, (unsigned long long)C.group_tests);
+    atomicAdd(&stats->tri_tests, (unsigned long long)C.tri_tests);
+    atomicAdd(&stats->analytic_tests, (unsigned long long)C.analytic_tests);
+    atomicAdd(&stats->knodes, (unsigned long long)C.knodes);
+    atomicAdd(&stats->kplanes, (unsigned long long)C.kplanes);
+  }
+}

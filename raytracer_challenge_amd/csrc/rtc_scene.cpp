@@ -17,16 +17,11 @@
 #include "scene_build.hpp"
 
 void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
-                      DStats* stats, bool count, hipStream_t stream, unsigned refill_blocks, unsigned long long* next_work);
-int rtc_v3_blocks_per_cu(void);
+                      DStats* stats, bool count, hipStream_t stream);
 void rtc_launch_quantize(const double* rgb, unsigned char* out, unsigned long long n, hipStream_t stream);
-int rtc_v1_block(void);
 void rtc_launch_wavefront(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, const DWave& W, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
                           DStats* stats, bool count, hipStream_t stream, unsigned blocks);
 uint64_t rtc_wavefront_work(const DCamera& cam, const DPixelMap& pm);
-#ifdef RTC_PROBE
-void rtc_launch_probe(int w, const DScene& S, const double* rays, unsigned long long n, double* hit_t, int* hit_prim, int* hit_k, hipStream_t stream);
-#endif
 
 static thread_local std::string g_rtc_err;
 static int rtc_fail(int code, const std::string& m) {
@@ -44,6 +39,7 @@ struct rtc_scene {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t marker[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool marker_recorded[8] = {false, false, false, false, false, false, false, false};
   std::vector<void*> allocs;
   uint64_t bytes = 0;
   DScene d{};
@@ -61,9 +57,7 @@ struct rtc_scene {
   double tune_ms[2] = {-1.0, -1.0};
   int tune_n[2] = {0, 0};
   int tune_choice = 0;
-  bool last_wavefront = false;
-  unsigned long long* d_next = nullptr;  // work counter of the refill variant (RTC_KERNEL=3)
-  unsigned max_blocks_v3 = 0;
+  bool wave_alloc_failed = false;  // the device refused the queues once: launches stay on the one-kernel path
   // wavefront path (RTC_KERNEL=4): queues and per-level arrays, grown on demand
   DWave wave{};
   void* wave_mem = nullptr;
@@ -92,8 +86,8 @@ namespace {
 
 int ensure_px(rtc_scene* s, uint64_t n, bool hits) {
   if (n > s->cap_px) {
-    if (s->d_rgb) { (void)hipFree(s->d_rgb); (void)hipFree(s->d_hit_t); (void)hipFree(s->d_hit_prim); (void)hipFree(s->d_hit_k); }
-    s->d_rgb = nullptr; s->cap_px = 0;
+    (void)hipFree(s->d_rgb); (void)hipFree(s->d_hit_t); (void)hipFree(s->d_hit_prim); (void)hipFree(s->d_hit_k);  // hipFree(nullptr) is a no-op
+    s->d_rgb = nullptr; s->d_hit_t = nullptr; s->d_hit_prim = nullptr; s->d_hit_k = nullptr; s->cap_px = 0;
     HIP_OK(hipMalloc((void**)&s->d_rgb, n * 3 * sizeof(double)));
     HIP_OK(hipMalloc((void**)&s->d_hit_t, n * sizeof(double)));
     HIP_OK(hipMalloc((void**)&s->d_hit_prim, n * sizeof(int)));
@@ -124,7 +118,19 @@ int ensure_wave(rtc_scene* s, uint64_t n_work, int fuel) {
   HIP_OK(hipStreamSynchronize(s->stream));
   if (s->wave_mem) (void)hipFree(s->wave_mem);
   s->wave_mem = nullptr; s->wave_cap = 0; s->wave_levels = 0;
-  HIP_OK(hipMalloc(&s->wave_mem, wave_bytes(cap, lv)));
+  {
+    // other owners of the device's memory (a host framework's allocator, other scenes) are not in the budget: ask the device
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && wave_bytes(cap, lv) > (uint64_t)free_b)
+      return rtc_fail(RTC_ERR_UNSUPPORTED, "the wavefront queues do not fit the device's free memory");
+    const hipError_t e = std::getenv("RTC_WF_FAIL_ALLOC") ? hipErrorOutOfMemory : hipMalloc(&s->wave_mem, wave_bytes(cap, lv));  // env: test hook
+    if (e != hipSuccess) {
+      (void)hipGetLastError();  // clear the sticky error: the launch continues on the one-kernel path
+      s->wave_mem = nullptr;
+      if (e == hipErrorOutOfMemory) return rtc_fail(RTC_ERR_UNSUPPORTED, "hipMalloc of the wavefront queues: out of memory");
+      return rtc_fail(RTC_ERR_DEVICE, std::string("hipMalloc of the wavefront queues: ") + hipGetErrorString(e));
+    }
+  }
   double* d = (double*)s->wave_mem;
   DWave& W = s->wave;
   W.rq[0] = d; d += 7 * cap;
@@ -179,44 +185,49 @@ int pick_path(rtc_scene* s, uint64_t sig, uint64_t n_work, bool will_sync, bool 
   return 1;
 }
 
+// Sticky error state of the scene (DStats tail): read and cleared together.
+int read_clear_sticky(rtc_scene* s, DStats* h) {
+  HIP_OK(hipMemcpy(h, s->d_stats, sizeof(*h), hipMemcpyDeviceToHost));
+  if (h->nan_ts || h->guard || h->wf_overflow)
+    HIP_OK(hipMemset((char*)s->d_stats + RTC_STATS_LAUNCH_BYTES, 0, sizeof(DStats) - RTC_STATS_LAUNCH_BYTES));
+  return RTC_OK;
+}
+
 int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb, bool want_hits, rtc_stats* stats, bool count, bool sync, int force = 0) {
   if (fuel < 0) fuel = 0;  // fuel <= 0 spawns nothing (src/world.rs:90,110)
   if (fuel > RTC_MAX_FUEL) return rtc_fail(RTC_ERR_INVALID, "fuel exceeds RTC_MAX_FUEL");
   HIP_OK(hipSetDevice(s->device));
-  HIP_OK(hipMemsetAsync(s->d_stats, 0, sizeof(DStats), s->stream));
+  // only the per-launch counters are zeroed: the error fields behind them accumulate until somebody reads them
+  HIP_OK(hipMemsetAsync(s->d_stats, 0, RTC_STATS_LAUNCH_BYTES, s->stream));
   HIP_OK(hipEventRecord(s->ev0, s->stream));
   const bool will_sync = sync || stats != nullptr;
   const bool tuned = force == 0 && s->kernel_version == 0;
   int path = force ? force : s->kernel_version;
   if (tuned) path = pick_path(s, launch_signature(cam, pm, fuel), rtc_wavefront_work(cam, pm), will_sync, pm.mode != 2);
+  if (path == 4 && s->wave_alloc_failed && force == 0) path = 1;
   const bool wavefront = path == 4 && pm.n > 0;
-  s->last_wavefront = wavefront;
   if (wavefront) {
     int rc = ensure_wave(s, rtc_wavefront_work(cam, pm), fuel);
-    if (rc == RTC_ERR_UNSUPPORTED && tuned) {  // does not fit the memory budget: this launch shape stays on the one-kernel path
-      s->tune_ms[1] = 1e30; s->tune_n[1] = 2; s->tune_choice = 1;
+    if (rc == RTC_ERR_UNSUPPORTED && force == 0) {
+      // does not fit the memory budget / the device's free memory: this launch shape stays on the one-kernel path (same bits)
+      if (tuned) { s->tune_ms[1] = 1e30; s->tune_n[1] = 2; s->tune_choice = 1; }
+      else s->wave_alloc_failed = true;
       return run(s, cam, pm, fuel, d_rgb, want_hits, stats, count, sync, 1);
     }
     if (rc != RTC_OK) return rc;
     HIP_OK(hipMemsetAsync(s->wave.counts, 0, RTC_WF_COUNTS * sizeof(uint32_t), s->stream));
     HIP_OK(hipEventRecord(s->ev0, s->stream));
     rtc_launch_wavefront(s->d, cam, pm, fuel, s->wave, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream, s->wave_blocks);
-  } else if (path != 3) {
-    rtc_launch_trace(s->d, cam, pm, fuel, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream, 0, s->d_next);
   } else {
-    // persistent v1 with per-lane refill: the work counter starts after the ids the grid's lanes take implicitly
-    unsigned blocks = s->max_blocks_v3;
-    uint64_t need = (pm.n + (uint64_t)rtc_v1_block() - 1) / (uint64_t)rtc_v1_block();
-    if (need < blocks) blocks = (unsigned)need;
-    unsigned long long start = (unsigned long long)blocks * (unsigned long long)rtc_v1_block();
-    HIP_OK(hipMemcpyAsync(s->d_next, &start, sizeof(start), hipMemcpyHostToDevice, s->stream));
-    HIP_OK(hipEventRecord(s->ev0, s->stream));
-    rtc_launch_trace(s->d, cam, pm, fuel, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream, blocks, s->d_next);
+    rtc_launch_trace(s->d, cam, pm, fuel, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream);
   }
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(s->ev1, s->stream));
   if (!sync && !stats) return RTC_OK;
   HIP_OK(hipStreamSynchronize(s->stream));
+  DStats h;
+  int rcs = read_clear_sticky(s, &h);
+  if (rcs != RTC_OK) return rcs;
   if (wavefront) {
     uint32_t overflow = 0;
     HIP_OK(hipMemcpy(&overflow, s->wave.counts + RTC_WF_OVERFLOW, sizeof(overflow), hipMemcpyDeviceToHost));
@@ -224,7 +235,8 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
       const uint64_t n_work = rtc_wavefront_work(cam, pm);
       if (s->wave_mul < 64 && wave_bytes(2ull * s->wave_mul * n_work, fuel + 1) <= wave_budget() && 2ull * s->wave_mul * n_work <= 0x7fffff00ull) {
         s->wave_mul *= 2;
-        return run(s, cam, pm, fuel, d_rgb, want_hits, stats, count, true, 4);
+        const int rc2 = run(s, cam, pm, fuel, d_rgb, want_hits, stats, count, true, 4);
+        if (rc2 != RTC_ERR_UNSUPPORTED) return rc2;  // (the larger queues were refused by the device: fall through)
       }
       if (tuned) { s->tune_ms[1] = 1e30; s->tune_n[1] = 2; s->tune_choice = 1; }
       return run(s, cam, pm, fuel, d_rgb, want_hits, stats, count, true, 1);
@@ -238,8 +250,6 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
     s->tune_n[k]++;
     if (s->tune_n[0] >= 2 && s->tune_n[1] >= 2) s->tune_choice = s->tune_ms[1] < s->tune_ms[0] ? 4 : 1;
   }
-  DStats h;
-  HIP_OK(hipMemcpy(&h, s->d_stats, sizeof(h), hipMemcpyDeviceToHost));
   if (stats) {
     float ms = 0.f;
     HIP_OK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
@@ -248,6 +258,7 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
     stats->rays_primary = h.rays_primary; stats->rays_shadow = h.rays_shadow; stats->rays_reflect = h.rays_reflect; stats->rays_refract = h.rays_refract;
     stats->rays_container = h.rays_container; stats->accel_nodes = h.accel_nodes; stats->group_tests = h.group_tests; stats->tri_tests = h.tri_tests;
     stats->analytic_tests = h.analytic_tests; stats->nan_ts = h.nan_ts;
+    stats->accel_nodes_kernarg = h.knodes; stats->analytic_tests_kernarg = h.kplanes;
     stats->kernel_ms = ms;
     stats->n_launches = wavefront ? 2u * (uint32_t)fuel + 4u : 1u;
   }
@@ -256,12 +267,7 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
     for (int i = 0; i < 32; i++) std::fprintf(stderr, " %llu", (unsigned long long)h.diag[i]);
     std::fprintf(stderr, "\n");
   }
-  if (h.guard) {
-    std::string info;
-    for (int i = 0; i < 8; i++) info += " " + std::to_string(h.guard_info[i]);
-    return rtc_fail(RTC_ERR_DEVICE, "traversal guard tripped (mask " + std::to_string(h.guard) + "; first: code it_kind it it_end value cur pc mode =" + info +
-                                        "): an index left its array; no pixel of this call is trustworthy");
-  }
+  if (h.guard) return rtc_fail(RTC_ERR_DEVICE, "traversal guard tripped (mask " + std::to_string(h.guard) + "): an index left its array; no pixel since the last check is trustworthy");
   if (h.nan_ts) return rtc_fail(RTC_ERR_NAN, "a NaN intersection t was produced (the reference panics in Intersection::sort, src/intersection.rs:124)");
   return RTC_OK;
 }
@@ -349,21 +355,16 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
   }
   HIP_OK(hipMalloc((void**)&s->d_stats, sizeof(DStats)));
   HIP_OK(hipMemset(s->d_stats, 0, sizeof(DStats)));
-  HIP_OK(hipMalloc((void**)&s->d_next, sizeof(unsigned long long)));
   {
-    // RTC_KERNEL selects the launch shape for A/B runs (both are the same HIP kernel template): 1 (default) = one pixel per lane,
-    // 8x8 tiles; 3 = persistent grid, lanes refill from a global work counter.  (2 was a persistent state machine with voted
-    // step kinds: 2.6x slower than 1 on every configuration, removed)
+    // RTC_KERNEL pins a device path for A/B runs and for the parity tests: 1 = one kernel per frame, 4 = wavefront kernels (every
+    // launch, pixel lists and explicit rays included); unset = measured choice per launch shape.
     const char* kv = std::getenv("RTC_KERNEL");
     const int kvi = kv ? std::atoi(kv) : 0;
-    s->kernel_version = (kvi == 1 || kvi == 3 || kvi == 4) ? kvi : 0;
+    s->kernel_version = (kvi == 1 || kvi == 4) ? kvi : 0;
     // hipDeviceGetAttribute, not hipGetDeviceProperties: the property struct's layout differs between ROCm releases and
     // this library may run on the HIP runtime PyTorch loaded first.
     int n_cu = 0;
     HIP_OK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device));
-    int per_cu3 = rtc_v3_blocks_per_cu();
-    if (const char* w = std::getenv("RTC_V3_BLOCKS_PER_CU")) per_cu3 = std::max(1, std::atoi(w));
-    s->max_blocks_v3 = (unsigned)std::max(1, n_cu * per_cu3);
     s->wave_blocks = (unsigned)std::max(1, n_cu * 32);
     if (const char* w = std::getenv("RTC_WF_BLOCKS_PER_CU")) s->wave_blocks = (unsigned)std::max(1, n_cu * std::atoi(w));
   }
@@ -377,8 +378,7 @@ void rtc_scene_destroy(rtc_scene* s) {
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   for (void* p : s->allocs) (void)hipFree(p);
   if (s->d_stats) (void)hipFree(s->d_stats);
-  if (s->d_rgb) { (void)hipFree(s->d_rgb); (void)hipFree(s->d_hit_t); (void)hipFree(s->d_hit_prim); (void)hipFree(s->d_hit_k); }
-  if (s->d_next) (void)hipFree(s->d_next);
+  (void)hipFree(s->d_rgb); (void)hipFree(s->d_hit_t); (void)hipFree(s->d_hit_prim); (void)hipFree(s->d_hit_k);
   if (s->wave_mem) (void)hipFree(s->wave_mem);
   if (s->d_idx) (void)hipFree(s->d_idx);
   if (s->d_rays) (void)hipFree(s->d_rays);
@@ -488,36 +488,6 @@ int rtc_trace_rays(rtc_scene* s, const double* rays, uint64_t n, int32_t fuel, d
   return RTC_OK;
 }
 
-#ifdef RTC_PROBE
-// Experiment entry: closest hits of n host rays with the slim kernel at register budget w; returns kernel ms (mean of reps).
-extern "C" double rtc_probe_closest(rtc_scene* s, const double* rays, uint64_t n, int w, int reps, rtc_hit* hits) {
-  if (hipSetDevice(s->device) != hipSuccess) return -1.0;
-  if (ensure_px(s, n, true) != RTC_OK) return -1.0;
-  if (n > s->cap_rays) {
-    if (s->d_rays) (void)hipFree(s->d_rays);
-    s->d_rays = nullptr; s->cap_rays = 0;
-    if (hipMalloc((void**)&s->d_rays, n * 6 * sizeof(double)) != hipSuccess) return -1.0;
-    s->cap_rays = n;
-  }
-  (void)hipMemcpyAsync(s->d_rays, rays, n * 6 * sizeof(double), hipMemcpyHostToDevice, s->stream);
-  rtc_launch_probe(w, s->d, s->d_rays, n, s->d_hit_t, s->d_hit_prim, s->d_hit_k, s->stream);  // warm-up
-  (void)hipEventRecord(s->ev0, s->stream);
-  for (int i = 0; i < reps; i++) rtc_launch_probe(w, s->d, s->d_rays, n, s->d_hit_t, s->d_hit_prim, s->d_hit_k, s->stream);
-  (void)hipEventRecord(s->ev1, s->stream);
-  if (hipStreamSynchronize(s->stream) != hipSuccess) return -1.0;
-  float ms = 0.f;
-  (void)hipEventElapsedTime(&ms, s->ev0, s->ev1);
-  if (hits) {
-    std::vector<double> t(n);
-    std::vector<int> p(n), k(n);
-    (void)hipMemcpy(t.data(), s->d_hit_t, n * sizeof(double), hipMemcpyDeviceToHost);
-    (void)hipMemcpy(p.data(), s->d_hit_prim, n * sizeof(int), hipMemcpyDeviceToHost);
-    (void)hipMemcpy(k.data(), s->d_hit_k, n * sizeof(int), hipMemcpyDeviceToHost);
-    for (uint64_t i = 0; i < n; i++) hits[i] = {t[i], p[i], k[i]};
-  }
-  return (double)ms / reps;
-}
-#endif
 
 int rtc_quantize_device(rtc_scene* s, const double* rgb_dev, uint64_t n_values, uint8_t* out_dev, int sync) {
   if (!s || (n_values && (!rgb_dev || !out_dev))) return rtc_fail(RTC_ERR_INVALID, "NULL argument");
@@ -571,37 +541,51 @@ uint64_t rtc_ppm(uint64_t hsize, uint64_t vsize, const uint8_t* rgb8, char* out,
   return (uint64_t)(p - out);
 }
 
-// Error flags of the launches since the last check (asynchronous launches do not read them back themselves).
+// Error state of every launch since the last check (or the last synchronous render, which reports and clears it too):
+// asynchronous launches (sync == 0, stats == NULL) do not read it back themselves.
 int rtc_scene_check(rtc_scene* s) {
   if (!s) return rtc_fail(RTC_ERR_INVALID, "NULL scene");
   HIP_OK(hipSetDevice(s->device));
   HIP_OK(hipStreamSynchronize(s->stream));
   DStats h;
-  HIP_OK(hipMemcpy(&h, s->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+  int rc = read_clear_sticky(s, &h);
+  if (rc != RTC_OK) return rc;
   if (h.guard) return rtc_fail(RTC_ERR_DEVICE, "traversal guard tripped (mask " + std::to_string(h.guard) + ")");
   if (h.nan_ts) return rtc_fail(RTC_ERR_NAN, "a NaN intersection t was produced (the reference panics in Intersection::sort, src/intersection.rs:124)");
-  if (s->last_wavefront && s->wave_mem) {
-    uint32_t overflow = 0;
-    HIP_OK(hipMemcpy(&overflow, s->wave.counts + RTC_WF_OVERFLOW, sizeof(overflow), hipMemcpyDeviceToHost));
-    if (overflow) return rtc_fail(RTC_ERR_UNSUPPORTED, "a wavefront ray queue overflowed in an unsynchronised launch: render this launch synchronously (falls back by itself)");
-  }
+  if (h.wf_overflow) return rtc_fail(RTC_ERR_UNSUPPORTED, "a wavefront ray queue overflowed in an unsynchronised launch: render this launch synchronously (falls back by itself)");
   return RTC_OK;
 }
 
+// Stream markers.  Every event is created with the scene and lives as long as it; a marker that was never recorded is an
+// error, not an undefined wait (hipEventSynchronize / hipEventElapsedTime on a never-recorded event).
+static int marker_slot(rtc_scene* s, int slot, bool need_recorded) {
+  if (!s) return rtc_fail(RTC_ERR_INVALID, "NULL scene");
+  if (slot < 0 || slot >= 8) return rtc_fail(RTC_ERR_INVALID, "marker slot out of range (0..7)");
+  if (need_recorded && !s->marker_recorded[slot]) return rtc_fail(RTC_ERR_INVALID, "marker slot " + std::to_string(slot) + " was never recorded");
+  return RTC_OK;
+}
 int rtc_scene_record(rtc_scene* s, int slot) {
-  if (!s || slot < 0 || slot >= 8) return rtc_fail(RTC_ERR_INVALID, "bad marker slot");
+  int rc = marker_slot(s, slot, false);
+  if (rc != RTC_OK) return rc;
   HIP_OK(hipSetDevice(s->device));
   HIP_OK(hipEventRecord(s->marker[slot], s->stream));
+  s->marker_recorded[slot] = true;
   return RTC_OK;
 }
 int rtc_scene_wait(rtc_scene* s, int slot) {
-  if (!s || slot < 0 || slot >= 8) return rtc_fail(RTC_ERR_INVALID, "bad marker slot");
+  int rc = marker_slot(s, slot, true);
+  if (rc != RTC_OK) return rc;
   HIP_OK(hipSetDevice(s->device));
   HIP_OK(hipEventSynchronize(s->marker[slot]));
   return RTC_OK;
 }
 int rtc_scene_elapsed_ms(rtc_scene* s, int from, int to, double* ms) {
-  if (!s || !ms || from < 0 || from >= 8 || to < 0 || to >= 8) return rtc_fail(RTC_ERR_INVALID, "bad marker slot");
+  int rc = marker_slot(s, from, true);
+  if (rc == RTC_OK) rc = marker_slot(s, to, true);
+  if (rc != RTC_OK) return rc;
+  if (!ms) return rtc_fail(RTC_ERR_INVALID, "NULL argument");
+  HIP_OK(hipSetDevice(s->device));
+  HIP_OK(hipEventSynchronize(s->marker[to]));  // both must have completed for hipEventElapsedTime
   float f = 0.f;
   HIP_OK(hipEventElapsedTime(&f, s->marker[from], s->marker[to]));
   *ms = f;

@@ -17,12 +17,14 @@ class RtcCameraC(C.Structure):
 
 
 class RtcStatsC(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("pixels", "rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "rays_container",
-                                          "accel_nodes", "group_tests", "tri_tests", "analytic_tests", "nan_ts")] + \
-               [("kernel_ms", C.c_double), ("n_launches", C.c_uint32), ("_pad", C.c_uint32)]
+    _COUNTERS = ("pixels", "rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "rays_container",
+                 "accel_nodes", "group_tests", "tri_tests", "analytic_tests", "nan_ts")
+    _fields_ = [(n, C.c_uint64) for n in _COUNTERS] + \
+               [("kernel_ms", C.c_double), ("n_launches", C.c_uint32), ("_pad", C.c_uint32),
+                ("accel_nodes_kernarg", C.c_uint64), ("analytic_tests_kernarg", C.c_uint64)]
 
     def as_dict(self):
-        d = {n: int(getattr(self, n)) for n, _ in self._fields_[:11]}
+        d = {n: int(getattr(self, n)) for n in self._COUNTERS + ("accel_nodes_kernarg", "analytic_tests_kernarg")}
         d["kernel_ms"] = float(self.kernel_ms)
         d["n_launches"] = int(self.n_launches)
         d["unique_rays"] = d["rays_primary"] + d["rays_shadow"] + d["rays_reflect"] + d["rays_refract"]
@@ -136,7 +138,7 @@ class DeviceRenderer:
         lib.rtc_scene_path_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         ch, a, b = C.c_int32(0), C.c_double(-1), C.c_double(-1)
         lib.rtc_scene_path_info(self.scene, C.byref(ch), C.byref(a), C.byref(b))
-        return {"path": {0: "undecided", 1: "one kernel", 3: "one kernel, refill", 4: "wavefront"}.get(ch.value, str(ch.value)),
+        return {"path": {0: "undecided", 1: "one kernel", 4: "wavefront"}.get(ch.value, str(ch.value)),
                 "one_kernel_ms": a.value, "wavefront_ms": b.value}
 
     def info(self) -> dict:

@@ -54,16 +54,10 @@ static int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double*
     }
     if (!done) {  // as the product does beyond its memory budget: render again with the one-kernel path
       std::memset(&st, 0, sizeof(st));
-      unsigned long long next = 0;
-      rtc_launch_trace(s->d, cam, pm, fuel, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr, 0, &next);
+      rtc_launch_trace(s->d, cam, pm, fuel, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr);
     }
-  } else if (!kv || kv[0] != '3') {
-    unsigned long long next = 0;
-    rtc_launch_trace(s->d, cam, pm, fuel, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr, 0, &next);
-  } else {  // v1 with per-lane refill, a small persistent grid
-    unsigned blocks = (unsigned)std::min<uint64_t>((pm.n + rtc_v1_block() - 1) / rtc_v1_block(), 3);
-    unsigned long long next = (unsigned long long)blocks * rtc_v1_block();
-    rtc_launch_trace(s->d, cam, pm, fuel, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr, blocks, &next);
+  } else {
+    rtc_launch_trace(s->d, cam, pm, fuel, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr);
   }
   if (hits) for (uint64_t i = 0; i < pm.n; i++) hits[i] = {t[i], p[i], k[i]};
   if (stats) {
@@ -72,6 +66,7 @@ static int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double*
     stats->rays_primary = st.rays_primary; stats->rays_shadow = st.rays_shadow; stats->rays_reflect = st.rays_reflect; stats->rays_refract = st.rays_refract;
     stats->rays_container = st.rays_container; stats->accel_nodes = st.accel_nodes; stats->group_tests = st.group_tests; stats->tri_tests = st.tri_tests;
     stats->analytic_tests = st.analytic_tests; stats->nan_ts = st.nan_ts;
+    stats->accel_nodes_kernarg = st.knodes; stats->analytic_tests_kernarg = st.kplanes;
     stats->n_launches = n_launches;
   }
   if (st.guard) return efail(RTC_ERR_DEVICE, "traversal guard tripped (mask " + std::to_string(st.guard) + ")");

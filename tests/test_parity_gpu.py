@@ -21,10 +21,10 @@ def test_hip_matches_oracle(hip, orc, name):
     assert_parity(hip, orc, world, cam, 5, label=name)
 
 
-@pytest.mark.parametrize("version", ["1", "3", "4"])
+@pytest.mark.parametrize("version", ["1", "4"])
 def test_hip_every_kernel_version(hip, orc, version, monkeypatch):
-    """RTC_KERNEL selects the launch shape at scene creation: 1 = pixel per lane (default), 3 = persistent grid with per-lane
-    refill.  Both must be bit-exact in hits on analytic, mesh, grouped, glass and CSG scenes."""
+    """RTC_KERNEL pins the device path at scene creation: 1 = one kernel per frame, 4 = wavefront kernels.  Both must be
+    bit-exact in hits on analytic, mesh, grouped, glass and CSG scenes."""
     monkeypatch.setenv("RTC_KERNEL", version)
     for name in ("synthetic_cones_grouped", "teapot_low", "nested_glass", "cube_lattice", "synthetic_mesh_small", "patterns_and_noise", "csg_scene"):
         cam, world = cases.SMALL_CASES[name]()
@@ -133,6 +133,54 @@ def test_hip_measured_path_choice(hip):
     dr.sync()
     dr.check()
     assert np.array_equal(out.cpu().numpy().reshape(-1, 3), full)
+
+
+def test_hip_error_state_is_sticky_across_async_launches(hip):
+    """A bad asynchronous launch (NaN camera -> NaN intersection t's) followed by a good one: rtc_scene_check() still reports
+    RTC_ERR_NAN (the flags accumulate until read), and a second check is clean."""
+    import torch
+    from raytracer_challenge_amd import RtwError
+    from raytracer_challenge_amd.device import DeviceRenderer
+    cam, world = scenes.chapter15_teapot("teapot_low.obj", 32, 18)   # planes are tested outside any accelerator: NaN rays reach them
+    nw = hip.build_world(world)
+    for version in ("1", "4"):
+        os.environ["RTC_KERNEL"] = version
+        try:
+            dr = DeviceRenderer(hip, nw, cam, device=0)
+        finally:
+            os.environ.pop("RTC_KERNEL")
+        out = torch.empty(cam.vsize * cam.hsize * 3, dtype=torch.float64, device="cuda:0")
+        good = dr.cam.transform_inv[0]
+        dr.cam.transform_inv[0] = float("nan")
+        dr.render_rows_async(5, 0, 1, cam.vsize, out)
+        dr.cam.transform_inv[0] = good
+        dr.render_rows_async(5, 0, 1, cam.vsize, out)
+        with pytest.raises(RtwError, match="NaN"):
+            dr.check()
+        dr.check()
+        # markers: waiting on / measuring a slot that was never recorded is an error, not an undefined wait
+        dr.record(1)
+        dr.wait(1)
+        with pytest.raises(RtwError, match="never recorded"):
+            dr.wait(5)
+        with pytest.raises(RtwError, match="never recorded"):
+            dr.elapsed_ms(1, 6)
+        with pytest.raises(RtwError, match="out of range"):
+            dr.record(8)
+
+
+def test_hip_wavefront_allocation_failure_falls_back(hip, orc, monkeypatch):
+    """The device refuses the wavefront queues (forced: RTC_WF_FAIL_ALLOC): the launch is rendered by the one-kernel path,
+    same bits, no error."""
+    cam, world = cases.nested_glass()
+    monkeypatch.setenv("RTC_KERNEL", "4")
+    ref = hip.render(hip.build_world(world), cam, 5)
+    monkeypatch.setenv("RTC_WF_FAIL_ALLOC", "1")
+    got = hip.render(hip.build_world(world), cam, 5)
+    assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[1], got[1])
+    monkeypatch.delenv("RTC_KERNEL")
+    got = hip.render(hip.build_world(world), cam, 5)     # measured choice: the wavefront candidate is dropped, not an error
+    assert np.array_equal(ref[0], got[0])
 
 
 def test_hip_config4_teapot_high_4k_fuel8(hip, orc):
