@@ -3,30 +3,42 @@
 1/2/4/8-GPU scaling").
 
 A *step* is one full frame: every rank traces its interleaved rows of the 1920x1080 image (fuel 5) with the HIP
-kernels and, for N > 1, the tiles are gathered to rank 0 over RCCL and de-interleaved.  Frames are software-pipelined
-(double-buffered tiles): the render of frame i overlaps the gather of frame i-1; all K renders and K gathers happen
-inside the timed region.  Rays are *unique* rays
-(SURVEY.md §8d): primary + shadow + reflection + refraction casts, counted by the kernel's counting variant in an
-untimed pass (the count is deterministic).  Total work is fixed as N grows -> "strong" scaling.
+kernels and, for N > 1, the tiles are gathered to rank 0 over RCCL and de-interleaved.  Frames are software-pipelined:
+F frames in flight per GPU (the SAME F at every N, default 3), each on its own copy of the uploaded scene and its own HIP
+stream; all K renders and K gathers happen inside the timed region.  Rays are *unique* rays: primary +
+shadow + reflection + refraction casts, counted by the kernels' counting variant in an untimed pass (the count is
+deterministic).  Total work is fixed as N grows -> "strong" scaling.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2|config3|config2_cones] [--no-cpu-baseline]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2|config3|...] [--inflight F] [--no-cpu-baseline] [--no-pmc]
 
-Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes of the dominant (only) kernel per launch
-(SURVEY.md §8d formula on the kernel's own counters) / its average duration: HIP events recorded on the stream the
-kernel is launched on around the K launches of the timed region, / K.  `cpu_baseline` = the CPU oracle (C++ restatement of the reference algorithm, NOT the Rust reference)
-timed on a bounded pixel sample of the same workload.
+`--gpus N` with N > 1 starts the N ranks itself (a child `python -m torch.distributed.run --nproc-per-node N bench.py ...`,
+started before this process touches a GPU) unless it already runs under torch.distributed.run (WORLD_SIZE set), as the
+driver launches it.  Rank 0 prints ONE JSON line:
+
+  value / ms_per_step   whole-job unique rays of K frames / wall time of the timed region (barrier + synchronize on both sides)
+  roofline              bound "hbm": algorithmic bytes per frame that go through the memory system (device.algorithmic_bytes:
+                        SURVEY §8d units on the kernels' own counters; kernel-argument-resident records count 0) / the frame's
+                        device time, measured with HIP events on the scene's stream over sequential launches; `traffic` =
+                        HBM bytes per frame from rocprofv3 PMC passes of THIS workload taken inside this run (child processes),
+                        corrected as profiles/pmc_calibration.json says; `hbm_traffic_frac` = traffic / device time / peak
+  valu                  what actually bounds the path: VALU pipe occupancy and SIMD lane utilisation from the same PMC passes
+  parity                the frame the timed path wrote vs the CPU oracle on the cpu_baseline's pixel sample
+  cpu_baseline          the CPU oracle (C++ restatement of the reference algorithm, NOT the Rust reference) on a bounded sample
+  config3               the same measurements for BASELINE configs[2] (the teapot + BVH scene), at N = 1
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+N_SIMD = 256 * 4        # same guide: 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9        # same guide: max clock (the chip runs below it under load: busy fractions are lower bounds)
 
 
 def make_workload(name):
@@ -51,29 +63,16 @@ def make_workload(name):
         path = os.path.join(tempfile.gettempdir(), "rtc_heightfield_708x708_12345.obj")
         cam, world = scenes.synthetic_mesh(path)   # writes the OBJ (999 698 triangles, one group) if it is not there yet
         desc = "BASELINE configs[4] on this many GPUs: 999 698-triangle synthetic smooth mesh + Fractal/Simplex noise patterns, 3840x2160, fuel 8"
+    elif name == "smoke":
+        cam, world = scenes.synthetic_analytic(n_primitives=64, seed=12345, cones=False, grouped=False, hsize=64, vsize=36)
+        desc = "rehearsal-size synthetic analytic scene, 64x36, fuel 5 (not a BASELINE config)"
     else:
         raise SystemExit("unknown workload %r" % name)
     return cam, world, desc
 
 
-def pmc_traffic(workload, path):
-    """HBM bytes per launch (one-kernel path) / per frame (wavefront path) measured with rocprofv3 PMC passes for this
-    workload on the device path this run uses (profiles/pmc_traffic.json), or None."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[workload]
-        if ("wavefront" in t.get("path", "")) != (path == "wavefront"):
-            return None, None
-        return t["fetch_bytes"] + t["write_bytes"], t["source"]
-    except Exception:
-        return None, None
-
-
-def capped_algorithmic_bytes(st, n_prims):
-    """the counted figure, never more than 4x the ideal one-descent figure (guards against a bad BVH)."""
-    import math
-    from raytracer_challenge_amd.device import algorithmic_bytes
-    ideal = 96 + 64 * math.ceil(math.log2(max(2, n_prims))) + 72 * 4
-    return min(algorithmic_bytes(st), 4 * ideal * st["unique_rays"] + 24 * st["pixels"])
+def default_fuel(workload):
+    return 8 if workload in ("config4", "config5") else 5
 
 
 def cpu_threads():
@@ -89,8 +88,107 @@ def cpu_threads():
     return max(1, min(n, int(os.environ.get("RTC_CPU_THREADS", "16"))))
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks as child processes (never exec: this process may already have touched a GPU)
+# ---------------------------------------------------------------------------------------------------------------------
+def self_launch(n):
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for l in p.stdout.splitlines():
+        if l.startswith("{") and '"metric"' in l:
+            line = l
+        else:
+            print(l, file=sys.stderr)
+    if line:
+        print(line, flush=True)
+    sys.exit(p.returncode if p.returncode else (0 if line else 1))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# rocprofv3 PMC passes of this workload, taken by child processes of this run (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE
+# do not fit one pass; PMC only ever with --kernel-trace)
+# ---------------------------------------------------------------------------------------------------------------------
+PMC_PASSES = [
+    ["FETCH_SIZE", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAVES", "SQ_BUSY_CYCLES"],
+    ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"],
+]
+
+
+def pmc_calibration():
+    """Bytes per counter unit for FETCH_SIZE / WRITE_SIZE in this path's access patterns (scripts/pmc_calibrate.hip measured on
+    known byte counts, as the guide prescribes for access widths other than 16 B per lane)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_calibration.json")))
+    except Exception:
+        return {"fetch_bytes_per_unit": 1024.0, "write_bytes_per_unit": 1024.0, "source": "uncalibrated: rocprofv3 reports KiB"}
+
+
+def frame_kernels(path, fuel):
+    """(kernel name prefix, launches per frame) of the timed (non-counting) kernels of a device path."""
+    if "wavefront" in path:
+        return [("wf_ts<false", fuel + 2), ("wf_shade<false", fuel + 1), ("wf_gather", 1)]
+    return [("rtc_trace_kernel<false", 1)]
+
+
+def pmc_measure(workload, fuel, path, timeout_s=240):
+    """Runs the PMC passes; returns {counter: value per FRAME of the chosen device path} (mean per dispatch x dispatches per
+    frame, per kernel, summed) plus per-kernel tables, or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    from collections import defaultdict
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    kernels = frame_kernels(path, fuel)
+    per_frame, per_kernel = defaultdict(float), {}
+    for counters in PMC_PASSES:
+        out = tempfile.mkdtemp(prefix="rtc_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+               "--pmc-child", "--workload", workload, "--fuel", str(fuel), "--steps", "3", "--warmup", "1", "--inflight", "1"]
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            p = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(out, ignore_errors=True)
+            return None, "rocprofv3 pass timed out"
+        if p.returncode != 0:
+            shutil.rmtree(out, ignore_errors=True)
+            return None, "rocprofv3 pass failed (rc %d): %s" % (p.returncode, p.stdout[-300:])
+        acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                kn = row.get("Kernel_Name", "").replace("void ", "")
+                for prefix, _ in kernels:
+                    if kn.startswith(prefix):
+                        c = acc[prefix][row["Counter_Name"]]
+                        c[0] += 1
+                        c[1] += float(row["Counter_Value"])
+        shutil.rmtree(out, ignore_errors=True)
+        for prefix, per in kernels:
+            for cn, (n, tot) in acc[prefix].items():
+                per_frame[cn] += tot / n * per
+                per_kernel.setdefault(prefix, {})[cn] = {"mean_per_dispatch": tot / n, "dispatches_profiled": n, "dispatches_per_frame": per}
+        missing = [c for c in counters if c not in per_frame]
+        if missing:
+            return None, "counters missing from the rocprofv3 output: %s" % missing
+    return {"per_frame": dict(per_frame), "per_kernel": per_kernel}, None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline + parity sample (the oracle: test infrastructure, used here only as the checker / the baseline)
+# ---------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(world, cam, fuel, target_seconds=30.0):  # the short probe over-estimates the per-pixel cost ~2.5x: ~12 s measured
-    """Oracle (CPU restatement) on a bounded, strided pixel sample of the same frame.  Returns the JSON object."""
+    """Oracle (CPU restatement) on a bounded, strided pixel sample of the same frame.  Returns (json object, idx, rgb, hits)."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import oracle
@@ -104,71 +202,69 @@ def cpu_baseline(world, cam, fuel, target_seconds=30.0):  # the short probe over
     n = int(min(total, max(4096, target_seconds / per_px)))
     stride = max(1, total // n)
     idx = np.arange(0, total, stride, dtype=np.uint64)
-    _, _, st = orc.render_timed(nw, cam, fuel, idx, threads=threads)
-    return {
+    rgb, hits, st = orc.render_timed(nw, cam, fuel, idx, threads=threads)
+    obj = {
         "value": st.unique_rays / st.seconds / 1e6, "unit": "Mrays/s", "cores": int(st.threads), "kind": "port",
         "sample": "every %d-th pixel of the frame (%d px, %.1f s): oracle = C++ restatement of the reference algorithm "
                   "(flat groups, all-hits + stable sort, per-light re-tracing), %d std::threads" % (stride, len(idx), st.seconds, threads),
         "reference_traced_mrays_per_s": st.traced_rays / st.seconds / 1e6,
     }
+    return obj, idx, rgb, hits
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="config2")
-    ap.add_argument("--fuel", type=int, default=None, help="recursion depth (default: 5; 8 for config4/config5)")
-    ap.add_argument("--inflight", type=int, default=0, help="frames in flight per GPU, each on its own scene copy and HIP stream "
-                    "(default: 1 on one GPU, 3 on several, where the per-rank frames are small and latency-bound)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--extra-workloads", default="config3", help="comma list measured (untimed region) and reported under 'extra' at N=1")
-    args = ap.parse_args()
+def parity_block(idx, ref_rgb, ref_hits, gpu_rgb_full, gpu_hits_full, timed_frame_equal):
+    """SURVEY §8(d) 'parity check accompanying every number': the oracle's sample against the same pixels of the GPU frame."""
+    import numpy as np
+    ii = idx.astype(np.int64)
+    g_rgb, g_hits = gpu_rgb_full[ii], gpu_hits_full[ii]
+    bad = (g_hits["prim"] != ref_hits["prim"]) | (g_hits["push_idx"] != ref_hits["push_idx"]) | (g_hits["t"].view(np.uint64) != ref_hits["t"].view(np.uint64))
+    return {"pixels": int(len(idx)), "max_abs_drgb": float(np.abs(g_rgb - ref_rgb).max()) if len(idx) else 0.0, "tolerance": 1e-5,
+            "primary_hit_mismatches": int(bad.sum()), "host_fallback_pixels": 0,
+            "timed_frame_equals_checked_frame": bool(timed_frame_equal),
+            "checked": "full frame rendered through rtc_render on the device path of the timed region, compared with the oracle on the cpu_baseline sample"}
 
-    if args.fuel is None:
-        args.fuel = 8 if args.workload in ("config4", "config5") else 5
-    import torch
-    import raytracer_challenge_amd as rt
-    from raytracer_challenge_amd.device import DeviceRenderer, algorithmic_bytes
 
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world_size != args.gpus:
-        if world_size == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world_size
-    dist = None
-    # RTC_BENCH_REHEARSE=1: rehearsal of the multi-rank code path on a one-GPU box (every rank on cuda:0, gloo gather through
-    # host memory).  Its numbers mean nothing; the driver's N-GPU runs never set it.
-    rehearse = world_size > 1 and os.environ.get("RTC_BENCH_REHEARSE") == "1"
-    if rehearse:
-        local_rank = 0
-    if world_size > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        if rehearse:
-            dist.init_process_group(backend="gloo")
+class Runtime:
+    """Where tiles live and how the device is synchronised.  The product runtime is the GPU (librtc_amd.so, HIP streams, RCCL).
+    RTC_BENCH_CPU_STANDIN=1 (tests/test_bench_cpu.py only) swaps in the CPU emulator of the kernel source (tests/cpu_emu, test
+    infrastructure) so that the launch / partition / gather / reporting code of this file can run without a GPU: such a run is a
+    rehearsal of the plumbing, never a measurement, and says so in its JSON line."""
+
+    def __init__(self, torch, local_rank, standin):
+        self.torch, self.local_rank, self.standin = torch, local_rank, standin
+        if standin:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from emu_lib import emu
+            self.backend = emu()
+            self.dev = torch.device("cpu")
         else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    gather_dev = torch.device("cpu") if rehearse else dev
+            import raytracer_challenge_amd as rt
+            torch.cuda.set_device(local_rank)
+            self.backend = rt.hip_backend()  # raises if the HIP library is missing
+            self.dev = torch.device("cuda", local_rank)
 
-    hip = rt.hip_backend()  # raises if the HIP library is missing
-    cam, world, desc = make_workload(args.workload)
-    # F frames in flight: F copies of the uploaded scene, each with its own HIP stream (and wavefront buffers), frames dealt
-    # round-robin.  A frame's per-level kernels are latency-bound at the small deep levels (and at the small per-rank frames of
-    # an N-GPU run); the next frames' kernels fill the chip meanwhile.
-    F = args.inflight if args.inflight > 0 else (1 if world_size == 1 else 3)
+    def synchronize(self):
+        if not self.standin:
+            self.torch.cuda.synchronize()
+
+    def renderer(self, world, cam):
+        from raytracer_challenge_amd.device import DeviceRenderer
+        return DeviceRenderer(self.backend, world, cam, device=self.local_rank, _cpu_standin=self.standin)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def measure(args, rtm, dist, workload, fuel, steps, warmup, F, rank, world_size, rehearse, want_pmc, want_cpu):
+    """One workload on this process group.  Returns the dict of measurements (rank 0: complete; other ranks: partial)."""
+    import numpy as np
+    from raytracer_challenge_amd.device import algorithmic_bytes
+    from raytracer_challenge_amd.parallel import FrameGatherer
+    torch, hip, dev = rtm.torch, rtm.backend, rtm.dev
+    gather_dev = torch.device("cpu") if rehearse else dev
+    cam, world, desc = make_workload(workload)
     nws = [hip.build_world(world) for _ in range(F)]
-    drs = [DeviceRenderer(hip, w, cam, device=local_rank) for w in nws]
+    drs = [rtm.renderer(w, cam) for w in nws]
     nw, dr = nws[0], drs[0]
     H, V = cam.hsize, cam.vsize
-    from raytracer_challenge_amd.parallel import FrameGatherer
     fg = FrameGatherer(H, V, rank, world_size, gather_dev, dist, n_buffers=F, tile_device=dev)
 
     def finish(i):
@@ -176,104 +272,202 @@ def main():
         drs[i % F].wait(0)
         if world_size > 1:
             fg.gather(i % F)
-            torch.cuda.current_stream().synchronize()  # tiles[i % F] is free again once the gather has consumed it
+            if not rtm.standin:
+                torch.cuda.current_stream().synchronize()  # tiles[i % F] is free again once the gather has consumed it
 
     def run_frames(k):
         """k full frames, software-pipelined: up to F renders in flight; the gather of frame i - F runs behind them."""
         for i in range(k):
             if i >= F:
                 finish(i - F)
-            drs[i % F].render_rows_async(args.fuel, rank, world_size, fg.n_rows, fg.tiles[i % F])
+            drs[i % F].render_rows_async(fuel, rank, world_size, fg.n_rows, fg.tiles[i % F])
             drs[i % F].record(0)
         for i in range(max(0, k - F), k):
             finish(i)
 
-    # untimed: counting variant -> unique rays + algorithmic bytes of this rank's launch
-    cst = dr.render_rows(args.fuel, rank, world_size, fg.n_rows, fg.tiles[0], count=True, sync=True)
+    def barrier():
+        if world_size > 1:
+            dist.barrier()
+        rtm.synchronize()
+        for d in drs:
+            d.sync()
+
+    # untimed: counting variant -> unique rays + work counters of this rank's launch
+    cst = dr.render_rows(fuel, rank, world_size, fg.n_rows, fg.tiles[0], count=True, sync=True)
     rays_local = torch.tensor([float(cst["unique_rays"])], dtype=torch.float64, device=gather_dev)
     if world_size > 1:
         dist.all_reduce(rays_local)
     rays_total = float(rays_local.item())
 
     # untimed: both device paths measured twice per renderer, the faster one kept
-    paths = [d.tune(args.fuel, rank, world_size, fg.n_rows, fg.tiles[j]) for j, d in enumerate(drs)]
+    paths = [d.tune(fuel, rank, world_size, fg.n_rows, fg.tiles[j]) for j, d in enumerate(drs)]
     path = paths[0]
-    run_frames(args.warmup)
+    run_frames(warmup)
     for d in drs:
         d.check()
-    if world_size > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    for d in drs:
-        d.sync()
-        d.record(2)                   # stream markers 2..3 bracket the timed region's launches on each renderer's own stream
+    barrier()
     t0 = time.perf_counter()
-    run_frames(args.steps)
-    for d in drs:
-        d.record(3)
-    for d in drs:
-        d.sync()
-    torch.cuda.synchronize()
-    if world_size > 1:
-        dist.barrier()
+    run_frames(steps)
+    barrier()
     elapsed = time.perf_counter() - t0
     for d in drs:
-        d.check()                     # NaN / guard / overflow flags of the timed launches
-    # device time per frame: throughput view (the timed region on the busiest stream / all frames) and latency view (a
-    # stream's region / the frames it rendered: what rocprofv3's per-kernel durations add up to)
-    used = [j for j in range(F) if j < args.steps]
-    region_ms = [drs[j].elapsed_ms(2, 3) for j in used]
-    frames_on = [len(range(j, args.steps, F)) for j in used]
-    kernel_ms = [max(region_ms) / max(1, args.steps)]
-    latency_ms = sum(r / f for r, f in zip(region_ms, frames_on)) / len(used)
+        d.check()                     # error state of EVERY launch of the timed region (sticky until read)
     el = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
     if world_size > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
+    # untimed: the frame's own device time, one frame at a time (what rocprofv3's per-kernel durations add up to): HIP events on
+    # the scene's stream around n_seq sequential launches
+    n_seq = max(5, min(50, steps))
+    dr.record(2)
+    for _ in range(n_seq):
+        dr.render_rows_async(fuel, rank, world_size, fg.n_rows, fg.tiles[0])
+    dr.record(3)
+    dr.sync()
+    dr.check()
+    seq_ms = dr.elapsed_ms(2, 3) / n_seq
+    timed_tile = fg.tiles[0].clone()
+
+    res = {"workload": workload, "desc": desc, "H": H, "V": V, "fuel": fuel, "steps": steps, "warmup": warmup, "elapsed": elapsed, "rays_total": rays_total,
+           "seq_ms": seq_ms, "path": path, "counters": cst, "n_lights": nw.n_lights, "primitives": nw.primitive_count, "info": dr.info(), "F": F}
+    if rank != 0:
+        return res
+    alg = algorithmic_bytes(cst, path["path"], nw.primitive_count)
+    achieved = alg["memory"] / (seq_ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": ("wavefront frame = wf_ts x%d + wf_shade x%d + wf_gather (dominant: wf_ts)" % (fuel + 2, fuel + 1)) if "wavefront" in path["path"] else "rtc_trace_kernel",
+            "kernel_ms_avg": seq_ms, "kernel_ms_measured_over": "%d sequential launches after the timed region, HIP events on the scene's stream" % n_seq,
+            "algorithmic_bytes_per_launch": alg["memory"], "algorithmic_bytes": alg, "path": path,
+            "counters_rank0": {k: cst[k] for k in ("pixels", "unique_rays", "rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "rays_container", "accel_nodes",
+                                                   "accel_nodes_kernarg", "group_tests", "tri_tests", "analytic_tests", "analytic_tests_kernarg")},
+            "note": "not the binding limit: the scene (%d B) is L2 / Infinity-Cache resident and most algorithmic bytes are served on chip; "
+                    "hbm_traffic_frac is the real HBM share, `valu` the pipe that binds" % dr.info()["scene_device_bytes"]}
+    res["roofline"] = roof
+    if world_size == 1:
+        if want_pmc:
+            pm, why = pmc_measure(workload, fuel, path["path"])
+            if pm is None:
+                roof["traffic_note"] = why
+            else:
+                cal = pmc_calibration()
+                pf = pm["per_frame"]
+                fetch, write = pf["FETCH_SIZE"] * cal["fetch_bytes_per_unit"], pf["WRITE_SIZE"] * cal["write_bytes_per_unit"]
+                roof["traffic"] = fetch + write
+                roof["traffic_detail"] = {"fetch_bytes": fetch, "write_bytes": write, "calibration": cal, "l2_hit_rate": pf["TCC_HIT_sum"] / max(1.0, pf["TCC_HIT_sum"] + pf["TCC_MISS_sum"]),
+                                          "source": "rocprofv3 --kernel-trace --pmc, two passes run by this bench invocation; per frame = mean per dispatch x dispatches per frame, per kernel"}
+                roof["hbm_traffic_frac"] = (fetch + write) / (seq_ms * 1e-3) / (HBM_PEAK_GBS * 1e9)
+                busy_cycles = 4.0 * pf["SQ_ACTIVE_INST_VALU"]   # the SQ counts quad-cycles
+                res["valu"] = {
+                    "bound": "valu issue (f64 vector pipe) x SIMD lane utilisation",
+                    "insts_valu_per_frame": pf["SQ_INSTS_VALU"],
+                    "valu_busy_frac": busy_cycles / (seq_ms * 1e-3 * CLOCK_HZ * N_SIMD),
+                    "lane_utilisation": pf["SQ_THREAD_CYCLES_VALU"] / (64.0 * max(1.0, pf["SQ_ACTIVE_INST_VALU"])),
+                    "wait_frac_of_wave_cycles": pf["SQ_WAIT_ANY"] / max(1.0, pf["SQ_WAVE_CYCLES"]),
+                    "cycles_per_valu_inst": busy_cycles / max(1.0, pf["SQ_INSTS_VALU"]),
+                    "formulae": "valu_busy_frac = 4 x SQ_ACTIVE_INST_VALU / (kernel s x 2.4 GHz x 1024 SIMDs); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); "
+                                "profiled clocks are lower than 2.4 GHz, so the busy fraction is a lower bound",
+                    "per_kernel": pm["per_kernel"],
+                }
+        # PCIe-inclusive figure: Image::par_render semantically returns host pixels (rtc_render: kernel + 24 B/px D2H)
+        hip.render(nw, cam, fuel, want_hits=False)
+        t1 = time.perf_counter()
+        n_h = 3
+        for _ in range(n_h):
+            rgb_full, hits_full = hip.render(nw, cam, fuel)
+        res["ms_per_step_incl_d2h"] = (time.perf_counter() - t1) / n_h * 1e3
+        if want_cpu:
+            base, idx, ref_rgb, ref_hits = cpu_baseline(world, cam, fuel)
+            res["cpu_baseline"] = base
+            same = bool(np.array_equal(timed_tile.cpu().numpy()[: H * V * 3].reshape(-1, 3), rgb_full))
+            res["parity"] = parity_block(idx, ref_rgb, ref_hits, rgb_full, hits_full, same)
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200, help="timed frames (default 200: >= 0.5 s of device time at ~3 ms/frame)")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="config2")
+    ap.add_argument("--fuel", type=int, default=None, help="recursion depth (default: 5; 8 for config4/config5)")
+    ap.add_argument("--inflight", type=int, default=3, help="frames in flight per GPU, each on its own scene copy and HIP stream; the same at every N")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC child passes (roofline.traffic = null)")
+    ap.add_argument("--extra-workloads", default="config3", help="comma list of further workloads measured in full after the headline one, at N=1")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.fuel is None:
+        args.fuel = default_fuel(args.workload)
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)          # does not return
+    args.gpus = world_size
+
+    import torch
+    standin = os.environ.get("RTC_BENCH_CPU_STANDIN") == "1"
+    dist = None
+    # RTC_BENCH_REHEARSE=1: rehearsal of the multi-rank code path on a one-GPU box (every rank on cuda:0, gloo gather through
+    # host memory).  Its numbers mean nothing; the driver's N-GPU runs never set it.
+    rehearse = world_size > 1 and (standin or os.environ.get("RTC_BENCH_REHEARSE") == "1")
+    if rehearse:
+        local_rank = 0
+    backend_name = None
+    if world_size > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if not standin:
+            torch.cuda.set_device(local_rank)
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend_name = dist.get_backend()
+    rtm = Runtime(torch, local_rank, standin)
+    if standin:
+        args.no_pmc = True
+
+    if args.pmc_child:  # profiled by the parent's rocprofv3: the frames of the workload, nothing else
+        measure(args, rtm, dist, args.workload, args.fuel, args.steps, args.warmup, 1, 0, 1, False, False, False)
+        return
+
+    F = max(1, args.inflight)
+    m = measure(args, rtm, dist, args.workload, args.fuel, args.steps, args.warmup, F, rank, world_size, rehearse,
+                want_pmc=not args.no_pmc, want_cpu=not args.no_cpu_baseline)
     if rank == 0:
-        # roofline per launch: a frame's own device time (latency view, comparable with rocprofv3's kernel durations); frames
-        # in flight overlap, so the chip-wide rate is the throughput view
-        throughput_ms = sum(kernel_ms) / len(kernel_ms)
-        avg_kernel_ms = latency_ms
-        alg_bytes = capped_algorithmic_bytes(cst, nw.primitive_count)
-        achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
+        H, V = m["H"], m["V"]
         out = {
-            "metric": "Mrays/s (unique rays: primary+shadow+reflection+refraction) at %dx%d depth-%d" % (H, V, args.fuel),
-            "value": rays_total * args.steps / elapsed / 1e6,
+            "metric": "Mrays/s (unique rays: primary+shadow+reflection+refraction) at %dx%d depth-%d" % (H, V, m["fuel"]),
+            "value": m["rays_total"] * m["steps"] / m["elapsed"] / 1e6,
             "unit": "Mrays/s",
-            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "n_gpus": world_size, "steps": m["steps"], "warmup": m["warmup"],
+            "ms_per_step": m["elapsed"] / m["steps"] * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": desc, "hsize": H, "vsize": V, "fuel": args.fuel, "lights": nw.n_lights, "primitives": nw.primitive_count,
+            "dtype": "f64", "data": "synthetic" if not standin else "synthetic; CPU STAND-IN REHEARSAL of the bench plumbing (kernel source emulated on the CPU): not a measurement",
+            "config": {"workload": m["desc"], "hsize": H, "vsize": V, "fuel": m["fuel"], "lights": m["n_lights"], "primitives": m["primitives"],
                        "partition": "rows interleaved by rank, RCCL gather to rank 0" if world_size > 1 else "single GPU",
-                       "unique_rays_per_frame": rays_total, "rays_per_pixel": rays_total / (H * V)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.workload, path["path"])[0] if world_size == 1 else None, "traffic_source": pmc_traffic(args.workload, path["path"])[1],
-                         "kernel": ("wavefront frame = wf_ts x%d + wf_shade x%d + wf_gather (dominant: wf_ts)" % (args.fuel + 2, args.fuel + 1))
-                                   if path["path"] == "wavefront" else "rtc_trace_kernel",
-                         "kernel_ms_avg": avg_kernel_ms, "frames_in_flight": F, "device_ms_per_frame_all_streams": throughput_ms,
-                         "achieved_all_streams": alg_bytes / (throughput_ms * 1e-3) / 1e9, "path": path, "algorithmic_bytes_per_launch": alg_bytes,
-                         "counters_rank0": {k: cst[k] for k in ("pixels", "unique_rays", "accel_nodes", "group_tests", "tri_tests", "analytic_tests", "rays_container")},
-                         "note": "scene (%d B) is L2/Infinity-Cache resident; real HBM traffic ~ framebuffer only (SURVEY.md §8d)" % dr.info()["scene_device_bytes"]},
-            "accelerator": dr.info(),
+                       "frames_in_flight": F, "process_group": {"world_size": world_size, "backend": backend_name},
+                       "unique_rays_per_frame": m["rays_total"], "rays_per_pixel": m["rays_total"] / (H * V)},
+            "roofline": m["roofline"],
+            "accelerator": m["info"],
         }
+        for k in ("valu", "parity", "cpu_baseline", "ms_per_step_incl_d2h"):
+            if k in m:
+                out[k] = m[k]
         if world_size == 1:
-            extra = {}
             for name in [w for w in args.extra_workloads.split(",") if w and w != args.workload]:
-                c2, w2, d2 = make_workload(name)
-                nw2 = hip.build_world(w2)
-                dr2 = DeviceRenderer(hip, nw2, c2, device=local_rank)
-                t2 = torch.zeros(c2.vsize * c2.hsize * 3, dtype=torch.float64, device=dev)
-                s2 = dr2.render_rows(args.fuel, 0, 1, c2.vsize, t2, count=True)
-                ms = [dr2.render_rows(args.fuel, 0, 1, c2.vsize, t2)["kernel_ms"] for _ in range(8)]  # the first four measure the paths
-                ms = sum(ms[4:]) / len(ms[4:])
-                extra[name] = {"workload": d2, "mrays_per_s_kernel": s2["unique_rays"] / ms / 1e3, "kernel_ms": ms, "unique_rays": s2["unique_rays"],
-                               "roofline_achieved_GBs": capped_algorithmic_bytes(s2, nw2.primitive_count) / (ms * 1e-3) / 1e9, "accelerator": dr2.info(), "path": dr2.path_info()}
-            out["extra"] = extra
-            if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(world, cam, args.fuel)
+                fuel2 = default_fuel(name)
+                e = measure(args, rtm, dist, name, fuel2, args.steps, args.warmup, F, 0, 1, False,
+                            want_pmc=not args.no_pmc, want_cpu=not args.no_cpu_baseline)
+                ent = {"workload": e["desc"], "value": e["rays_total"] * e["steps"] / e["elapsed"] / 1e6, "unit": "Mrays/s", "steps": e["steps"],
+                       "ms_per_step": e["elapsed"] / e["steps"] * 1e3, "unique_rays_per_frame": e["rays_total"], "roofline": e["roofline"], "accelerator": e["info"]}
+                for k in ("valu", "parity", "cpu_baseline", "ms_per_step_incl_d2h"):
+                    if k in e:
+                        ent[k] = e[k]
+                out[name] = ent
         print(json.dumps(out), flush=True)
     if world_size > 1:
         dist.barrier()

@@ -168,6 +168,25 @@ int rtc_render(rtc_scene*, const rtc_camera*, int32_t fuel, const uint64_t* pixe
 int rtc_render_rows_device(rtc_scene*, const rtc_camera*, int32_t fuel, uint32_t row_first, uint32_t row_step, uint32_t n_rows,
                            double* rgb_dev, rtc_stats* stats, int count_stats, int sync);
 
+/* ---- N GPUs of one process ----------------------------------------------------------------------------------------
+ * For the caller of Image::par_render (src/image.rs:65-81) that owns several devices.  An rtc_multi holds one replica of the
+ * scene per listed device (a device may be listed more than once — two replicas on one GPU — which is how a one-GPU box
+ * exercises the whole path).  rtc_render_multi: replica k traces image rows k, k + n, ... on its own device and stream (no
+ * exchange while tracing: pixels are independent, src/image.rs:68-73); the dense tiles are pulled to the FIRST listed device over
+ * xGMI (peer copies behind per-replica events), de-interleaved there, and the whole image (hsize*vsize*3 doubles, row-major) is
+ * copied to `rgb` (host).  Same pixels, bit for bit, as rtc_render on one device.  stats (optional): counters summed over the
+ * replicas (counting kernel variants), kernel_ms = the slowest replica.
+ * One process per GPU + RCCL (bench.py, raytracer_challenge_amd/parallel.py) is the other way to use N GPUs; both partition alike. */
+typedef struct rtc_multi rtc_multi;
+int rtc_multi_create(const rtc_scene_desc* desc, const int* devices, int n_devices, rtc_multi** out);
+void rtc_multi_destroy(rtc_multi*);
+int rtc_multi_device_count(const rtc_multi*);
+int rtc_render_multi(rtc_multi*, const rtc_camera*, int32_t fuel, double* rgb, rtc_stats* stats);
+/* Same, image left on the first listed device (rgb_dev: hsize*vsize*3 doubles there).  Asynchronous unless sync != 0: queue
+ * several frames, then rtc_multi_sync() waits for all replicas and returns (and clears) their error state. */
+int rtc_render_multi_device(rtc_multi*, const rtc_camera*, int32_t fuel, double* rgb_dev, int sync);
+int rtc_multi_sync(rtc_multi*);
+
 /* World::color_at(ray, fuel) for n rays {ox,oy,oz,dx,dy,dz} (host arrays). */
 int rtc_trace_rays(rtc_scene*, const double* rays, uint64_t n, int32_t fuel, double* rgb, rtc_hit* hits, rtc_stats* stats);
 

@@ -246,6 +246,23 @@ void rtc_launch_quantize(const double* rgb, unsigned char* out, unsigned long lo
 }
 
 
+// Multi-GPU gather, last step: image row k + n j  <-  row j of replica k's dense tile in the slab.
+__global__ void __launch_bounds__(256) rtc_deinterleave_kernel(const double* __restrict__ slab, double* __restrict__ image, unsigned rowlen, unsigned vsize, unsigned n,
+                                                               unsigned max_rows) {
+  const unsigned long long total = (unsigned long long)vsize * rowlen;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * blockDim.x) {
+    const unsigned y = (unsigned)(i / rowlen), x = (unsigned)(i % rowlen);
+    image[i] = slab[((unsigned long long)(y % n) * max_rows + y / n) * rowlen + x];
+  }
+}
+void rtc_launch_deinterleave(const double* slab, double* image, unsigned rowlen, unsigned vsize, unsigned n, unsigned max_rows, hipStream_t stream) {
+  const unsigned long long total = (unsigned long long)vsize * rowlen;
+  if (total == 0) return;
+  unsigned long long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(rtc_deinterleave_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slab, image, rowlen, vsize, n, max_rows);
+}
+
 // One-kernel path: one lane per work id (tile padding included).
 void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
                       DStats* stats, bool count, hipStream_t stream) {

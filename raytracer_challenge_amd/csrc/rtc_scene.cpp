@@ -19,6 +19,7 @@
 void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
                       DStats* stats, bool count, hipStream_t stream);
 void rtc_launch_quantize(const double* rgb, unsigned char* out, unsigned long long n, hipStream_t stream);
+void rtc_launch_deinterleave(const double* slab, double* image, unsigned rowlen, unsigned vsize, unsigned n, unsigned max_rows, hipStream_t stream);
 void rtc_launch_wavefront(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, const DWave& W, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
                           DStats* stats, bool count, hipStream_t stream, unsigned blocks);
 uint64_t rtc_wavefront_work(const DCamera& cam, const DPixelMap& pm);
@@ -596,6 +597,210 @@ int rtc_scene_sync(rtc_scene* s) {
   if (!s) return rtc_fail(RTC_ERR_INVALID, "NULL scene");
   HIP_OK(hipSetDevice(s->device));
   HIP_OK(hipStreamSynchronize(s->stream));
+  return RTC_OK;
+}
+
+// ---- N GPUs of one process (include/rtc.h) ---------------------------------------------------------------------
+struct rtc_multi {
+  std::vector<rtc_scene*> scenes;   // one replica per listed device
+  std::vector<double*> tiles;       // replica k's dense rows k, k + n, ... on ITS device
+  std::vector<uint64_t> tile_cap;
+  std::vector<hipEvent_t> done;     // replica k's tile is complete (recorded on its stream)
+  std::vector<hipEvent_t> copied;   // the first device has pulled replica k's tile (recorded on the first replica's stream): the
+  std::vector<char> copied_valid;   //   replica's next frame waits for it before it overwrites the tile
+  double* slab = nullptr;           // first device: n x max_rows x hsize x 3
+  double* image = nullptr;          // first device: vsize x hsize x 3
+  uint64_t slab_cap = 0, image_cap = 0;
+};
+
+namespace {
+int multi_fail(rtc_multi* m, int rc) { (void)m; return rc; }
+
+// Lets replica s decide its device path for this launch shape (the measured choice needs synchronous launches).
+int ensure_tuned(rtc_scene* s, const DCamera& dc, const DPixelMap& pm, int fuel, double* d_rgb) {
+  if (s->kernel_version != 0) return RTC_OK;
+  for (int i = 0; i < 4; i++) {
+    if (s->tune_choice != 0 && s->tune_sig == launch_signature(dc, pm, fuel)) break;
+    int rc = run(s, dc, pm, fuel, d_rgb, false, nullptr, false, true);
+    if (rc != RTC_OK) return rc;
+  }
+  return RTC_OK;
+}
+
+int render_multi(rtc_multi* m, const rtc_camera* cam, int32_t fuel, double* rgb_dev_out, double* rgb_host, rtc_stats* stats, bool sync) {
+  if (!m || !cam) return rtc_fail(RTC_ERR_INVALID, "NULL argument");
+  if (cam->hsize == 0 || cam->vsize == 0) return rtc_fail(RTC_ERR_INVALID, "empty camera");
+  const uint32_t n = (uint32_t)m->scenes.size();
+  const uint64_t H = cam->hsize, V = cam->vsize, rowlen = H * 3;
+  if (rowlen > 0xffffffffull || V > 0xffffffffull) return rtc_fail(RTC_ERR_INVALID, "image too large");
+  const uint64_t max_rows = (V + n - 1) / n;
+  rtc_scene* s0 = m->scenes[0];
+  DCamera dc;
+  to_dcam(*cam, &dc);
+  // buffers: a tile per replica on its own device; slab and image on the first device
+  for (uint32_t k = 0; k < n; k++) {
+    rtc_scene* s = m->scenes[k];
+    if (max_rows * rowlen > m->tile_cap[k]) {
+      HIP_OK(hipSetDevice(s->device));
+      HIP_OK(hipStreamSynchronize(s->stream));
+      (void)hipFree(m->tiles[k]);
+      m->tiles[k] = nullptr; m->tile_cap[k] = 0;
+      HIP_OK(hipMalloc((void**)&m->tiles[k], max_rows * rowlen * sizeof(double)));
+      m->tile_cap[k] = max_rows * rowlen;
+    }
+  }
+  HIP_OK(hipSetDevice(s0->device));
+  if ((uint64_t)n * max_rows * rowlen > m->slab_cap) {
+    HIP_OK(hipStreamSynchronize(s0->stream));
+    (void)hipFree(m->slab);
+    m->slab = nullptr; m->slab_cap = 0;
+    HIP_OK(hipMalloc((void**)&m->slab, (uint64_t)n * max_rows * rowlen * sizeof(double)));
+    m->slab_cap = (uint64_t)n * max_rows * rowlen;
+  }
+  if (!rgb_dev_out && V * rowlen > m->image_cap) {
+    HIP_OK(hipStreamSynchronize(s0->stream));
+    (void)hipFree(m->image);
+    m->image = nullptr; m->image_cap = 0;
+    HIP_OK(hipMalloc((void**)&m->image, V * rowlen * sizeof(double)));
+    m->image_cap = V * rowlen;
+  }
+  double* image = rgb_dev_out ? rgb_dev_out : m->image;
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  // every replica traces its interleaved rows on its own device and stream; nothing is exchanged while tracing
+  for (uint32_t k = 0; k < n; k++) {
+    rtc_scene* s = m->scenes[k];
+    DPixelMap pm{};
+    const uint64_t rows = k < V ? (V - k + n - 1) / n : 0;
+    pm.n = rows * H; pm.mode = 2; pm.row_first = k; pm.row_step = n;
+    if (pm.n == 0) continue;
+    if (m->copied_valid[k]) {  // frames queued back to back: the previous frame's gather still reads this tile
+      HIP_OK(hipSetDevice(s->device));
+      HIP_OK(hipStreamWaitEvent(s->stream, m->copied[k], 0));
+    }
+    int rc = ensure_tuned(s, dc, pm, fuel, m->tiles[k]);
+    if (rc != RTC_OK) return rc;
+    rtc_stats st;
+    rc = run(s, dc, pm, fuel, m->tiles[k], false, stats ? &st : nullptr, stats != nullptr, false);
+    if (rc != RTC_OK) return rc;
+    if (stats) {
+      stats->pixels += st.pixels; stats->rays_primary += st.rays_primary; stats->rays_shadow += st.rays_shadow; stats->rays_reflect += st.rays_reflect;
+      stats->rays_refract += st.rays_refract; stats->rays_container += st.rays_container; stats->accel_nodes += st.accel_nodes; stats->group_tests += st.group_tests;
+      stats->tri_tests += st.tri_tests; stats->analytic_tests += st.analytic_tests; stats->nan_ts += st.nan_ts; stats->n_launches += st.n_launches;
+      stats->accel_nodes_kernarg += st.accel_nodes_kernarg; stats->analytic_tests_kernarg += st.analytic_tests_kernarg;
+      stats->kernel_ms = std::max(stats->kernel_ms, st.kernel_ms);
+    }
+    HIP_OK(hipSetDevice(s->device));
+    HIP_OK(hipEventRecord(m->done[k], s->stream));
+  }
+  // gather: the first device's stream waits for each tile and pulls it over xGMI into its slot of the slab, then one
+  // de-interleave pass writes the image (row k + n j  <-  slab[k][j])
+  HIP_OK(hipSetDevice(s0->device));
+  for (uint32_t k = 0; k < n; k++) {
+    const uint64_t rows = k < V ? (V - k + n - 1) / n : 0;
+    if (rows == 0) continue;
+    rtc_scene* s = m->scenes[k];
+    HIP_OK(hipStreamWaitEvent(s0->stream, m->done[k], 0));
+    double* dst = m->slab + (uint64_t)k * max_rows * rowlen;
+    if (s->device == s0->device) HIP_OK(hipMemcpyAsync(dst, m->tiles[k], rows * rowlen * sizeof(double), hipMemcpyDeviceToDevice, s0->stream));
+    else HIP_OK(hipMemcpyPeerAsync(dst, s0->device, m->tiles[k], s->device, rows * rowlen * sizeof(double), s0->stream));
+    HIP_OK(hipEventRecord(m->copied[k], s0->stream));
+    m->copied_valid[k] = 1;
+  }
+  rtc_launch_deinterleave(m->slab, image, (unsigned)rowlen, (unsigned)V, n, (unsigned)max_rows, s0->stream);
+  HIP_OK(hipGetLastError());
+  if (rgb_host) HIP_OK(hipMemcpyAsync(rgb_host, image, V * rowlen * sizeof(double), hipMemcpyDeviceToHost, s0->stream));
+  if (!sync && !rgb_host) return RTC_OK;
+  HIP_OK(hipStreamSynchronize(s0->stream));
+  for (uint32_t k = 0; k < n; k++) {
+    int rc = rtc_scene_check(m->scenes[k]);   // error state of every replica's launches
+    if (rc == RTC_ERR_UNSUPPORTED) {          // an unsynchronised wavefront launch overflowed its queues: once more, synchronously (falls back by itself)
+      const uint64_t rows = k < V ? (V - k + n - 1) / n : 0;
+      DPixelMap pm{};
+      pm.n = rows * H; pm.mode = 2; pm.row_first = k; pm.row_step = n;
+      rc = run(m->scenes[k], dc, pm, fuel, m->tiles[k], false, nullptr, false, true);
+      if (rc != RTC_OK) return rc;
+      return render_multi(m, cam, fuel, rgb_dev_out, rgb_host, stats, true);
+    }
+    if (rc != RTC_OK) return rc;
+  }
+  return RTC_OK;
+}
+}  // namespace
+
+int rtc_multi_create(const rtc_scene_desc* desc, const int* devices, int n_devices, rtc_multi** out) {
+  if (!desc || !devices || !out || n_devices <= 0) return rtc_fail(RTC_ERR_INVALID, "NULL argument / no devices");
+  *out = nullptr;
+  std::unique_ptr<rtc_multi> m(new rtc_multi());
+  for (int k = 0; k < n_devices; k++) {
+    rtc_scene* s = nullptr;
+    int rc = rtc_scene_create(desc, devices[k], &s);
+    if (rc != RTC_OK) { rtc_multi_destroy(m.release()); return rc; }
+    m->scenes.push_back(s);
+    m->tiles.push_back(nullptr);
+    m->tile_cap.push_back(0);
+    hipEvent_t e = nullptr;
+    if (hipSetDevice(devices[k]) != hipSuccess || hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      rtc_multi_destroy(m.release());
+      return rtc_fail(RTC_ERR_DEVICE, "hipEventCreate failed");
+    }
+    m->done.push_back(e);
+    hipEvent_t c = nullptr;
+    if (hipSetDevice(devices[0]) != hipSuccess || hipEventCreateWithFlags(&c, hipEventDisableTiming) != hipSuccess) {
+      rtc_multi_destroy(m.release());
+      return rtc_fail(RTC_ERR_DEVICE, "hipEventCreate failed");
+    }
+    m->copied.push_back(c);
+    m->copied_valid.push_back(0);
+  }
+  // direct xGMI copies into the first device where the platform allows them (hipMemcpyPeerAsync stages through the host otherwise)
+  (void)hipSetDevice(devices[0]);
+  for (int k = 1; k < n_devices; k++) {
+    int can = 0;
+    if (devices[k] != devices[0] && hipDeviceCanAccessPeer(&can, devices[0], devices[k]) == hipSuccess && can) {
+      if (hipDeviceEnablePeerAccess(devices[k], 0) != hipSuccess) (void)hipGetLastError();  // already enabled: fine
+    }
+  }
+  *out = m.release();
+  return RTC_OK;
+}
+
+void rtc_multi_destroy(rtc_multi* m) {
+  if (!m) return;
+  for (size_t k = 0; k < m->scenes.size(); k++) {
+    rtc_scene* s = m->scenes[k];
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (k < m->tiles.size()) (void)hipFree(m->tiles[k]);
+    if (k < m->done.size() && m->done[k]) (void)hipEventDestroy(m->done[k]);
+  }
+  for (hipEvent_t c : m->copied) if (c) (void)hipEventDestroy(c);
+  if (!m->scenes.empty()) {
+    (void)hipSetDevice(m->scenes[0]->device);
+    (void)hipFree(m->slab);
+    (void)hipFree(m->image);
+  }
+  for (rtc_scene* s : m->scenes) rtc_scene_destroy(s);
+  delete m;
+}
+
+int rtc_multi_device_count(const rtc_multi* m) { return m ? (int)m->scenes.size() : 0; }
+
+int rtc_render_multi(rtc_multi* m, const rtc_camera* cam, int32_t fuel, double* rgb, rtc_stats* stats) {
+  if (!rgb) return rtc_fail(RTC_ERR_INVALID, "NULL argument");
+  return render_multi(m, cam, fuel, nullptr, rgb, stats, true);
+}
+
+int rtc_render_multi_device(rtc_multi* m, const rtc_camera* cam, int32_t fuel, double* rgb_dev, int sync) {
+  if (!rgb_dev) return rtc_fail(RTC_ERR_INVALID, "NULL argument");
+  return render_multi(m, cam, fuel, rgb_dev, nullptr, nullptr, sync != 0);
+}
+
+int rtc_multi_sync(rtc_multi* m) {
+  if (!m) return rtc_fail(RTC_ERR_INVALID, "NULL argument");
+  for (rtc_scene* s : m->scenes) {
+    int rc = rtc_scene_check(s);
+    if (rc != RTC_OK) return rc;
+  }
   return RTC_OK;
 }
 

@@ -19,6 +19,7 @@ struct rtw_world {
   WorldH w;
   rtc_scene* scene = nullptr;  // cached flatten+upload; dropped on edit
   int device = 0;
+  std::unique_ptr<Flat> flat;  // rtw_world_flatten_desc: the arrays behind the descriptor it handed out
   ~rtw_world() { if (scene) rtc_scene_destroy(scene); }
 };
 
@@ -201,6 +202,16 @@ int rtw_world_flatten_counts(rtw_world* w, uint32_t counts[8]) {
   rtc_scene_desc d = f.desc();
   counts[0] = d.n_nodes; counts[1] = d.n_prims; counts[2] = d.n_xforms; counts[3] = d.n_limits;
   counts[4] = d.n_tris; counts[5] = d.n_materials; counts[6] = d.n_pattern_nodes; counts[7] = d.n_lights;
+  return 0;
+}
+
+// Flatten only (no device): the descriptor a Rust shim would hand to rtc_scene_create; its arrays live in the world handle until
+// the next call / the world's release.  Works without a GPU (tests compare it with a foreign flattener's output).
+int rtw_world_flatten_desc(rtw_world* w, rtc_scene_desc* out) {
+  w->flat.reset(new Flat());
+  Flattener fl(*w->flat);
+  if (!fl.run(w->w)) return fail("flatten: " + w->flat->error);
+  *out = w->flat->desc();
   return 0;
 }
 

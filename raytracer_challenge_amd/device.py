@@ -31,26 +31,50 @@ class RtcStatsC(C.Structure):
         return d
 
 
-# algorithmic bytes per unit of work
-BYTES_RAY = 64 + 32          # ray in + hit out
-BYTES_NODE = 128             # 4-wide accelerator node (a reference group box test is charged the same)
-BYTES_TRI = 72               # p1, e1, e2 (f64)
-BYTES_ANALYTIC = 112         # 3x4 f64 matrix + params
-BYTES_PIXEL = 24             # framebuffer write (3 x f64)
+# Algorithmic bytes per unit of work (with the record sizes this build really uses).  Only
+# records that the kernels fetch or store with vector memory instructions count; what travels in the kernel arguments (scalar
+# loads: plane records, each BVH's root node) is reported separately and counted as 0 bytes.
+UNIT_BYTES = {
+    "ray": 96,        # wavefront path only: 64 B queue record in + 32 B hit record out per unique ray (the one-kernel path keeps rays in registers)
+    "node": 128,      # one 4-wide accelerator node (DBvhNode4)
+    "group_box": 48,  # one reference group box (BoundingBox::intersects operands)
+    "triangle": 72,   # p1, e1, e2 (f64)
+    "analytic": 128,  # one intersection record (DPrimI: rows 0-2 of transform_inv + limits + tags)
+    "pixel": 24,      # framebuffer write (3 x f64)
+}
+KERNARG_BYTES = {"node": 128, "plane": 48}
 
 
-def algorithmic_bytes(st: dict) -> int:
-    """Bytes one launch must move by the accounting of SURVEY.md §8(d), from the kernel's own work counters."""
-    rays = st["unique_rays"]
-    return (BYTES_RAY * rays + BYTES_NODE * (st["accel_nodes"] + st["group_tests"]) + BYTES_TRI * st["tri_tests"]
-            + BYTES_ANALYTIC * st["analytic_tests"] + BYTES_PIXEL * st["pixels"])
+def algorithmic_bytes(st: dict, path: str, n_prims: int = 0) -> dict:
+    """Bytes one launch must move through the memory system by the accounting above, from the kernel's own work counters
+    (rtc_stats of the counting variant).  `memory` is what roofline.achieved uses: never more than 4x the ideal
+    one-descent figure (guards against a bad accelerator)."""
+    import math
+    wavefront = "wavefront" in path
+    by_unit = {
+        "ray": UNIT_BYTES["ray"] * st["unique_rays"] if wavefront else 0,
+        "node": UNIT_BYTES["node"] * (st["accel_nodes"] - st["accel_nodes_kernarg"]),
+        "group_box": UNIT_BYTES["group_box"] * st["group_tests"],
+        "triangle": UNIT_BYTES["triangle"] * st["tri_tests"],
+        "analytic": UNIT_BYTES["analytic"] * (st["analytic_tests"] - st["analytic_tests_kernarg"]),
+        "pixel": UNIT_BYTES["pixel"] * st["pixels"],
+    }
+    counted = sum(by_unit.values())
+    ideal = 96 + 64 * math.ceil(math.log2(max(2, n_prims))) + 72 * 4
+    cap = 4 * ideal * st["unique_rays"] + UNIT_BYTES["pixel"] * st["pixels"]
+    return {"memory": min(counted, cap), "counted": counted, "cap_4x_ideal": cap,
+            "kernarg": KERNARG_BYTES["node"] * st["accel_nodes_kernarg"] + KERNARG_BYTES["plane"] * st["analytic_tests_kernarg"],
+            "by_unit": by_unit, "unit_bytes": UNIT_BYTES}
 
 
 class DeviceRenderer:
     """One flattened+uploaded scene on one GPU plus a camera; renders interleaved rows into caller-owned HBM."""
 
-    def __init__(self, backend: Backend, world: NativeWorld, camera: Camera, device: int = 0):
-        if backend.name != "hip":
+    def __init__(self, backend: Backend, world: NativeWorld, camera: Camera, device: int = 0, _cpu_standin: bool = False):
+        # _cpu_standin: tests only (tests/test_bench_cpu.py): the CPU emulator of the kernel source behind the same rtc_* symbols,
+        # host tensors as "device" buffers, to rehearse the multi-rank plumbing without a GPU.  Never set by the product.
+        self._cpu_standin = bool(_cpu_standin) and backend.name == "hip-emu-cpu"
+        if backend.name != "hip" and not self._cpu_standin:
             raise RtwError("DeviceRenderer needs the HIP backend, got %r" % backend.name)
         lib = backend.lib
         lib.rtw_world_scene.restype = C.c_void_p
@@ -87,7 +111,7 @@ class DeviceRenderer:
                     want_stats: bool = True) -> dict:
         """Rows row_first, row_first+row_step, ... (n_rows) -> out_tensor (float64, n_rows*hsize*3, on this scene's GPU)."""
         need = n_rows * self.camera.hsize * 3
-        if out_tensor.numel() < need or out_tensor.element_size() != 8 or not out_tensor.is_cuda:
+        if out_tensor.numel() < need or out_tensor.element_size() != 8 or not (out_tensor.is_cuda or self._cpu_standin):
             raise RtwError("output tensor must be a float64 device tensor with >= %d elements" % need)
         st = RtcStatsC()
         rc = self.backend.lib.rtc_render_rows_device(self.scene, C.byref(self.cam), int(fuel), int(row_first), int(row_step), int(n_rows),
@@ -103,7 +127,7 @@ class DeviceRenderer:
     def render_rows_async(self, fuel: int, row_first: int, row_step: int, n_rows: int, out_tensor):
         """Queue a render on the scene's stream and return immediately (errors are reported by check())."""
         need = n_rows * self.camera.hsize * 3
-        if out_tensor.numel() < need or out_tensor.element_size() != 8 or not out_tensor.is_cuda:
+        if out_tensor.numel() < need or out_tensor.element_size() != 8 or not (out_tensor.is_cuda or self._cpu_standin):
             raise RtwError("output tensor must be a float64 device tensor with >= %d elements" % need)
         self._rc(self.backend.lib.rtc_render_rows_device(self.scene, C.byref(self.cam), int(fuel), int(row_first), int(row_step), int(n_rows),
                                                         C.c_void_p(out_tensor.data_ptr()), None, 0, 0), "rtc_render_rows_device")

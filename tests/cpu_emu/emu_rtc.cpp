@@ -8,6 +8,7 @@
 #include "../../raytracer_challenge_amd/csrc/rtc_kernels.hip"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <memory>
 #include <string>
@@ -19,6 +20,7 @@
 struct rtc_scene {
   rtb::HostArrays H;
   DScene d;
+  double marker_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wall clock at rtc_scene_record (launches are synchronous here)
 };
 static thread_local std::string g_err;
 static int efail(int c, const std::string& m) { g_err = m; return c; }
@@ -123,9 +125,17 @@ int rtc_quantize_device(rtc_scene*, const double* rgb, uint64_t n, uint8_t* out,
 int rtc_quantize(rtc_scene* s, const double* rgb, uint64_t n, uint8_t* out) { return rtc_quantize_device(s, rgb, n, out, 1); }
 int rtc_scene_sync(rtc_scene*) { return RTC_OK; }
 int rtc_scene_check(rtc_scene*) { return RTC_OK; }
-int rtc_scene_record(rtc_scene*, int) { return RTC_OK; }
+int rtc_scene_record(rtc_scene* s, int slot) {
+  if (!s || slot < 0 || slot >= 8) return efail(RTC_ERR_INVALID, "bad marker slot");
+  s->marker_ms[slot] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  return RTC_OK;
+}
 int rtc_scene_wait(rtc_scene*, int) { return RTC_OK; }
-int rtc_scene_elapsed_ms(rtc_scene*, int, int, double* ms) { if (ms) *ms = 0.0; return RTC_OK; }
+int rtc_scene_elapsed_ms(rtc_scene* s, int from, int to, double* ms) {
+  if (!s || !ms || from < 0 || from >= 8 || to < 0 || to >= 8) return efail(RTC_ERR_INVALID, "bad marker slot");
+  *ms = s->marker_ms[to] - s->marker_ms[from];
+  return RTC_OK;
+}
 void rtc_scene_path_info(const rtc_scene*, int32_t* choice, double* one_kernel_ms, double* wavefront_ms) {
   const char* kv = std::getenv("RTC_KERNEL");
   if (choice) *choice = kv ? std::atoi(kv) : 1;
