@@ -184,7 +184,7 @@ struct DStats {  // device-side counters (atomically accumulated per wave)
   unsigned long long accel_nodes, group_tests, tri_tests, analytic_tests;
   unsigned long long knodes;    // of accel_nodes: BVH root nodes read from the kernel arguments (scalar loads, no memory traffic)
   unsigned long long kplanes;   // of analytic_tests: plane records read from the kernel arguments
-  unsigned long long diag[32];  // RTC_DIAG builds only: region cycles / lane-utilisation sums (scripts/diag_report.py)
+  unsigned long long diag[64];  // RTC_DIAG builds only: region cycles / lane-utilisation sums (scripts/diag_report.py)
   // sticky error state: accumulated over every launch since the last rtc_scene_check() / synchronous read-back, which clear it
   unsigned long long nan_ts;       // NaN intersection t's seen (-> RTC_ERR_NAN)
   unsigned long long guard;        // bit mask of tripped traversal guards (0 = none)
@@ -196,7 +196,7 @@ struct DStats {  // device-side counters (atomically accumulated per wave)
 
 #define RTC_MAX_FUEL 16
 
-// Wavefront path (rtc_kernels.hip, wf_* kernels): rays of one bounce level live in a queue; per level a traversal launch
+// Wavefront path (rtc_device.hpp / rtc_kernels.hip, wf_* kernels): rays of one bounce level live in a queue; per level a traversal launch
 // (closest hits of the level + shadow rays and lighting of the previous level) and a shading launch (hit state, pattern
 // colour, child rays into the other queue), so the traversal kernel carries no shading state (half the registers of the
 // one-kernel path -> twice the resident waves).  All arrays are SoA rows of `cap` elements.  A ray's colour contribution is
@@ -210,20 +210,44 @@ struct DStats {  // device-side counters (atomically accumulated per wave)
 #ifndef RTC_WF_CHUNK
 #define RTC_WF_CHUNK 64u       // work items per chunk: one wave pass (larger chunks leave waves idle at the small, deep levels: 256 -> +25 %)
 #endif
+#define RTC_WF_MISS (-2)        // child row 0 of a ray that hit nothing: no contribution was written for it, it has no children
 struct DWave {
   double* rq[2];        // ray queues (level parity): 7 rows ox oy oz dx dy dz weight
   double* h_t;          // per ray of the level: closest hit t
   int32_t* h_prim;      //   primitive (-1 miss / padding)
-  double* h_n12;        //   2 rows: n1, n2
-  double* sr[2];        // shade records (compact; level parity): 13 rows point(3) eye(3) normal(3) colour(3) weight
-  int32_t* sr_mat[2];   //   material index
-  int32_t* sr_node[2];  //   ray index within the level
-  double* contrib;      // (levels) x 3 rows: colour contribution of each ray (own surface, later + children)
-  int32_t* child;       // (levels) x 2 rows: index of the reflected / refracted child ray in the next level (-1 none)
+  double* h_n12;        //   2 rows: n1, n2 — written and read only for hits on transparent surfaces that can still spawn rays
+  double* sr;           // shade records (compact): 9 rows over-point(3) normal(3) colour(3); the eye vector and the path weight
+                        //   are read back from the ray queue (eye = -direction), which still holds the level while its shadow pass runs
+  int32_t* sr_mat;      //   material index
+  int32_t* sr_node;     //   ray index within the level
+  double* contrib;      // (levels) x 3 rows: colour contribution of each ray that hit something (written by the shadow pass)
+  int32_t* child;       // (levels) x 2 rows: index of the reflected / refracted child ray in the next level (-1 none); row 0 = RTC_WF_MISS: no hit
   uint32_t* counts;     // RTC_WF_COUNTS counters: [level] rays of the level, [32 + level] shade records, [63] overflow flag, [64..] chunk cursors
   uint32_t cap;
   uint32_t pad;
 };
+// Bytes of the arrays above for `cap` elements per row and `levels` levels, and the carving of one allocation into them (shared
+// by rtc_scene.cpp and the CPU emulator of the kernels).  Per element at fuel 5: 50 doubles + 17 ints = 468 B.
+static inline uint64_t dwave_bytes(uint64_t cap, int levels) {
+  return cap * (uint64_t)(7 + 7 + 1 + 2 + 9 + 3 * levels) * sizeof(double) + (cap * (uint64_t)(1 + 1 + 1 + 2 * levels) + RTC_WF_COUNTS) * sizeof(int32_t);
+}
+static inline void dwave_carve(DWave* W, void* mem, uint64_t cap, int levels) {
+  double* d = (double*)mem;
+  W->rq[0] = d; d += 7 * cap;
+  W->rq[1] = d; d += 7 * cap;
+  W->h_t = d; d += cap;
+  W->h_n12 = d; d += 2 * cap;
+  W->sr = d; d += 9 * cap;
+  W->contrib = d; d += 3 * (uint64_t)levels * cap;
+  int32_t* q = (int32_t*)d;
+  W->h_prim = q; q += cap;
+  W->sr_mat = q; q += cap;
+  W->sr_node = q; q += cap;
+  W->child = q; q += 2 * (uint64_t)levels * cap;
+  W->counts = (uint32_t*)q;
+  W->cap = (uint32_t)cap;
+  W->pad = 0;
+}
 #ifndef RTC_BVH_STACK
 #define RTC_BVH_STACK 64
 #endif

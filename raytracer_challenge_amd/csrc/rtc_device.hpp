@@ -67,6 +67,14 @@
 #define RTC_WF_LANES 64u
 #endif
 #define DINF (__builtin_inf())
+// RTC_LAUNDER(x): the compiler may not assume it knows x's value any more.  Used on a work item's index right after a traversal:
+// without it every output address derived from the index before the traversal (hipcc computes them all up front) stays live
+// across it, and at a 128-register budget that meant ~60 dwords spilled to scratch and reloaded per ray.
+#ifdef RTC_EMU
+#define RTC_LAUNDER(x) do {} while (0)
+#else
+#define RTC_LAUNDER(x) asm volatile("" : "+v"(x))
+#endif
 static inline unsigned rtc_stack_bytes(const DScene& S) { return (unsigned)S.bvh_stack * RTC_BLOCK * (unsigned)sizeof(int); }
 
 namespace {
@@ -103,7 +111,7 @@ struct Counters {
 // diag[2r+1] += 1 per participation; diag[16+2j] += active lanes, diag[16+2j+1] += 1 per executed iteration of loop j.
 #ifdef RTC_DIAG
 // accumulated per block in LDS (one wave per block: no cross-wave contention in the hot loops), flushed once at kernel end
-__shared__ unsigned long long s_diag[32];
+__shared__ unsigned long long s_diag[64];
 #define DIAG_T0() diag_t0_ = __builtin_amdgcn_s_memtime()
 #define DIAG_REGION(r) do { unsigned long long t1_ = __builtin_amdgcn_s_memtime(); atomicAdd(&s_diag[2 * (r)], t1_ - diag_t0_); atomicAdd(&s_diag[2 * (r) + 1], 1ull); diag_t0_ = t1_; } while (0)
 #define DIAG_SPAN_BEGIN() unsigned long long span_t0_ = __builtin_amdgcn_s_memtime()
@@ -116,6 +124,10 @@ __shared__ unsigned long long s_diag[32];
 #define DIAG_SPAN_END(r) do {} while (0)
 #define DIAG_LOOP(j) do {} while (0)
 #endif
+
+// f64::powf (src/shape.rs:453).  Out of line: inlined, the library routine's ~50 f64 polynomial constants are hoisted to the top of
+// the calling kernel and spilled to scratch from there (wf_ts: 2/3 of its spill traffic), for a call that only lit highlights make.
+__device__ __noinline__ double rtc_pow(double a, double b) { return pow(a, b); }
 
 // Rust f64::max/min: a NaN operand is ignored.
 __device__ __forceinline__ double rmax(double a, double b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
@@ -228,6 +240,13 @@ __device__ __forceinline__ void accept(Trav& T, Counters& C, int prim, int n, co
   }
 }
 
+// Plane (src/shape.rs:621-633), t = -oy / dy: true when the quotient is certainly a normal negative number (operands of opposite
+// sign, no underflow to -0, which would pass `t >= 0`), so that no pass but the container pass (which counts intersections
+// behind the origin too) can use it: about half of all plane tests end here, without the f64 division and the hit bookkeeping.
+__device__ __forceinline__ bool plane_behind(const Trav& T, double oy, double dy) {
+  return T.mode != MODE_CONTAINERS && ((oy > 0.0) != (dy < 0.0)) && fabs(oy) > 1e-290 && fabs(dy) < 1e17;
+}
+
 // Geometry::intersect_triangle (src/shape.rs:824-860); o = object-space ray
 __device__ __forceinline__ int tri_hit(const double* __restrict__ g, const Ray& o, double& t, double& u, double& v) {
   double p1x = g[0], p1y = g[1], p1z = g[2], e1x = g[3], e1y = g[4], e1z = g[5], e2x = g[6], e2y = g[7], e2z = g[8];
@@ -248,79 +267,64 @@ __device__ __forceinline__ int tri_hit(const double* __restrict__ g, const Ray& 
 // Geometry::intersect (src/shape.rs:862-885) for one primitive; returns the number of pushes, in push order.
 __device__ __forceinline__ int prim_hits(const DScene& S, const DPrimI& P, const Ray& o, double* t, double& u, double& v) {
   int n = 0;
-  switch (P.geom) {
-    case 0: {  // sphere :592-619
-      double a = o.dx * o.dx + o.dy * o.dy + o.dz * o.dz;
-      double b = 2.0 * (o.dx * o.ox + o.dy * o.oy + o.dz * o.oz);
-      double c = (o.ox * o.ox + o.oy * o.oy + o.oz * o.oz) - 1.0;
-      double disc = b * b - 4.0 * a * c;
-      if (disc < 0.0) return 0;
-      double sq = sqrt(disc);
-      t[0] = (-b - sq) / (2.0 * a);
-      t[1] = (-b + sq) / (2.0 * a);
-      return 2;
-    }
-    case 1: {  // plane :621-633
-      if (fabs(o.dy - 0.0) < EPS) return 0;
-      t[0] = -o.oy / o.dy;
-      return 1;
-    }
-    case 2: {  // cube :655-679
-      double xa, xb, ya, yb, za, zb;
-      cube_axis(o.ox, o.dx, -1.0, 1.0, xa, xb);
-      cube_axis(o.oy, o.dy, -1.0, 1.0, ya, yb);
-      cube_axis(o.oz, o.dz, -1.0, 1.0, za, zb);
-      double t_min = rmax(rmax(xa, ya), za);
-      double t_max = rmin(rmin(xb, yb), zb);
-      if (t_min <= t_max) { t[0] = t_min; t[1] = t_max; return 2; }
-      return 0;
-    }
-    case 3:
-    case 4: {  // cylinder :724-768, cone :770-822
-      double mn = P.mn, mx = P.mx;
-      bool cone = P.geom == 4;
-      double a, b, c;
-      bool walls;
-      if (!cone) {
-        a = o.dx * o.dx + o.dz * o.dz;
-        walls = !(fabs(a - 0.0) < EPS);
-        b = 2.0 * o.ox * o.dx + 2.0 * o.oz * o.dz;
-        c = o.ox * o.ox + o.oz * o.oz - 1.0;
-      } else {
-        a = o.dx * o.dx - o.dy * o.dy + o.dz * o.dz;
-        b = 2.0 * o.ox * o.dx - 2.0 * o.oy * o.dy + 2.0 * o.oz * o.dz;
-        c = o.ox * o.ox - o.oy * o.oy + o.oz * o.oz;
-        bool a0 = fabs(a - 0.0) < EPS, b0 = fabs(b - 0.0) < EPS;
-        walls = !a0;
-        if (a0 && !b0) t[n++] = -c / (2.0 * b);  // single-root branch :812-818
-      }
-      if (walls) {
-        double disc = b * b - 4.0 * a * c;
-        if (disc >= 0.0) {
-          double sq = sqrt(disc);
-          double t0 = (-b - sq) / (2.0 * a);
-          double y0 = o.oy + t0 * o.dy;
-          if (mn < y0 && y0 < mx) t[n++] = t0;
-          double t1 = (-b + sq) / (2.0 * a);
-          double y1 = o.oy + t1 * o.dy;
-          if (mn < y1 && y1 < mx) t[n++] = t1;
-        }
-      }
-      // intersect_cap :681-722 (cylinder radii 1,1; cone radii min,max)
-      if ((P.flags & 2u) && !(fabs(o.dy - 0.0) < EPS)) {
-        double r0 = cone ? mn : 1.0, r1 = cone ? mx : 1.0;
-        double tc = (mn - o.oy) / o.dy;
-        double x = o.ox + tc * o.dx, z = o.oz + tc * o.dz;
-        if ((x * x + z * z) <= r0 * r0) t[n++] = tc;
-        tc = (mx - o.oy) / o.dy;
-        x = o.ox + tc * o.dx; z = o.oz + tc * o.dz;
-        if ((x * x + z * z) <= r1 * r1) t[n++] = tc;
-      }
-      return n;
-    }
-    default:  // triangles :824-860
-      return tri_hit(S.tri_geo + 9 * P.data, o, t[0], u, v);
+  if (P.geom == 1) {  // plane :621-633
+    if (fabs(o.dy - 0.0) < EPS) return 0;
+    t[0] = -o.oy / o.dy;
+    return 1;
   }
+  if (P.geom == 2) {  // cube :655-679
+    DIAG_LOOP(14);
+    double xa, xb, ya, yb, za, zb;
+    cube_axis(o.ox, o.dx, -1.0, 1.0, xa, xb);
+    cube_axis(o.oy, o.dy, -1.0, 1.0, ya, yb);
+    cube_axis(o.oz, o.dz, -1.0, 1.0, za, zb);
+    double t_min = rmax(rmax(xa, ya), za);
+    double t_max = rmin(rmin(xb, yb), zb);
+    if (t_min <= t_max) { t[0] = t_min; t[1] = t_max; return 2; }
+    return 0;
+  }
+  if (P.geom >= 5) return tri_hit(S.tri_geo + 9 * P.data, o, t[0], u, v);  // triangles :824-860
+  // Sphere :592-619, cylinder :724-768, cone :770-822: one quadratic a t^2 + b t + c = 0 for the three of them, so that lanes
+  // holding different kinds share the square root and the two divisions (a wave's leaf tests are a mix of kinds; each kind alone
+  // ran at ~20 % of the lanes).  The coefficients keep each kind's own operation order, bit for bit:
+  //   sphere    a = (dx dx + dy dy) + dz dz    b = 2 ((dx ox + dy oy) + dz oz)              c = ((ox ox + oy oy) + oz oz) - 1
+  //   cylinder  a =  dx dx + dz dz             b = 2 ox dx + 2 oz dz  = 2 (ox dx + oz dz)   c =  (ox ox + oz oz) - 1
+  //   cone      a = (dx dx - dy dy) + dz dz    b = (2 ox dx - 2 oy dy) + 2 oz dz = 2 (...)  c =  (ox ox - oy oy) + oz oz
+  // (x + 0.0 = x, x - 0.0 = x, and scaling by 2 commutes with rounding, so the shared expressions below give the same bits.)
+  DIAG_LOOP(13);
+  const bool sph = P.geom == 0, cone = P.geom == 4;
+  const double mn = P.mn, mx = P.mx;
+  const double ydd = o.dy * o.dy, ydo = o.dy * o.oy, yoo = o.oy * o.oy;
+  const double a = (o.dx * o.dx + (sph ? ydd : (cone ? -ydd : 0.0))) + o.dz * o.dz;
+  const double b = 2.0 * ((o.dx * o.ox + (sph ? ydo : (cone ? -ydo : 0.0))) + o.dz * o.oz);
+  const double c = ((o.ox * o.ox + (sph ? yoo : (cone ? -yoo : 0.0))) + o.oz * o.oz) - (cone ? 0.0 : 1.0);
+  const bool a0 = fabs(a - 0.0) < EPS;
+  if (cone && a0 && !(fabs(b - 0.0) < EPS)) t[n++] = -c / (2.0 * b);  // single-root branch :812-818
+  const double disc = b * b - 4.0 * a * c;
+  // sphere: `if disc < 0 { return }` lets a NaN discriminant through; cylinder / cone: `if disc >= 0` does not
+  if (sph ? !(disc < 0.0) : (!a0 && disc >= 0.0)) {
+    const double sq = sqrt(disc);
+    const double t0 = (-b - sq) / (2.0 * a);
+    const double t1 = (-b + sq) / (2.0 * a);
+    if (sph) { t[0] = t0; t[1] = t1; return 2; }
+    const double y0 = o.oy + t0 * o.dy;
+    if (mn < y0 && y0 < mx) t[n++] = t0;
+    const double y1 = o.oy + t1 * o.dy;
+    if (mn < y1 && y1 < mx) t[n++] = t1;
+  }
+  if (sph) return 0;
+  // intersect_cap :681-722 (cylinder radii 1,1; cone radii min,max)
+  if ((P.flags & 2u) && !(fabs(o.dy - 0.0) < EPS)) {
+    DIAG_LOOP(15);
+    double r0 = cone ? mn : 1.0, r1 = cone ? mx : 1.0;
+    double tc = (mn - o.oy) / o.dy;
+    double x = o.ox + tc * o.dx, z = o.oz + tc * o.dz;
+    if ((x * x + z * z) <= r0 * r0) t[n++] = tc;
+    tc = (mx - o.oy) / o.dy;
+    x = o.ox + tc * o.dx; z = o.oz + tc * o.dz;
+    if ((x * x + z * z) <= r1 * r1) t[n++] = tc;
+  }
+  return n;
 }
 
 // Shape::intersect (src/shape.rs:414-417) for one primitive.
@@ -338,13 +342,14 @@ __device__ __forceinline__ void visit_prim(const DScene& S, int prim, const Ray&
   const DPrimI P = S.pisect[prim];
   if (FEAT >= 2 && P.gcond >= 0 && !groups_pass(S, P.gcond, r, T, C)) return;
   const double* __restrict__ m = P.m;
+  if (policy == 0) { DIAG_LOOP(9); } else if (policy == 1) { DIAG_LOOP(10); } else { DIAG_LOOP(11); }
   if (P.geom == 1) {
     // Plane (src/shape.rs:621-633) only reads origin.y and direction.y of the object-space ray: evaluate that one row of
     // Ray::transform, in the same order, and skip the other two.
     C.analytic_tests++;
     double oy = m[4] * r.ox + m[5] * r.oy + m[6] * r.oz + m[7] * 1.0;
     double dy = m[4] * r.dx + m[5] * r.dy + m[6] * r.dz + m[7] * 0.0;
-    if (fabs(dy - 0.0) < EPS) return;
+    if (fabs(dy - 0.0) < EPS || plane_behind(T, oy, dy)) return;
     double t = -oy / dy;
     accept(T, C, prim, 1, &t);
     return;
@@ -358,6 +363,7 @@ __device__ __forceinline__ void visit_prim(const DScene& S, int prim, const Ray&
     if (P.geom == 2) quirk = fabs(dx) < EPS || fabs(dy) < EPS || fabs(dz) < EPS;
     else if (P.geom == 4) quirk = fabs((dx * dx - dy * dy + dz * dz) - 0.0) < EPS;
     if (!quirk) return;
+    DIAG_LOOP(12);
   }
   Ray o = to_object(m, r);
   if (policy == 1) {
@@ -375,6 +381,7 @@ __device__ __forceinline__ void visit_prim(const DScene& S, int prim, const Ray&
 // Direction-grid culled quirk scan (device_scene.h OP_QGRID).  The cell lookup must mirror build_quirk_grid().
 template <int FEAT>
 __device__ __forceinline__ void quirk_grid_scan(const DScene& S, const DQuirkGrid G, const Ray& r, Trav& T, Counters& C) {
+  DIAG_LOOP(21);
   double ax = fabs(r.dx), ay = fabs(r.dy), az = fabs(r.dz);
   double len2 = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
   if (!(len2 >= RTC_QGRID_MIN_LEN * RTC_QGRID_MIN_LEN) || !(len2 < DINF)) {
@@ -493,30 +500,30 @@ __device__ __forceinline__ void node_step(const float4 lox, const float4 loy, co
   cur = c0;
 }
 
-// kroot / kframe: the root node and the frame of this BVH from the kernel arguments (DScene.kaux; scalar loads) or nullptr.
-template <bool MESH, int FEAT>
-__device__ __forceinline__ void bvh_walk(const DScene& S, int root, int frame, const Ray& world, const Ray& o, Trav& T, Counters& C, int* __restrict__ stack, int stride,
-                                         const DBvhNode4* kroot = nullptr, const double* kframe = nullptr) {
-  Frame32 F;
-  make_frame(kframe ? kframe : S.bvh_frame + 4 * frame, o, F);
+// First step of a walk whose root node travels in the kernel arguments (DScene.kaux; scalar loads): every lane starts at the
+// root, so its boxes need no vector load.
+__device__ __forceinline__ void walk_root_k(const DBvhNode4& R, const Frame32& F, const Trav& T, Counters& C, int& cur, int& sp, int* __restrict__ stack, int stride) {
+  C.accel_nodes++;
+  C.knodes++;
+  float lo, hi;
+  t_interval32(T, lo, hi);
+  const float4 lox = {R.lox[0], R.lox[1], R.lox[2], R.lox[3]}, loy = {R.loy[0], R.loy[1], R.loy[2], R.loy[3]};
+  const float4 loz = {R.loz[0], R.loz[1], R.loz[2], R.loz[3]}, hix = {R.hix[0], R.hix[1], R.hix[2], R.hix[3]};
+  const float4 hiy = {R.hiy[0], R.hiy[1], R.hiy[2], R.hiy[3]}, hiz = {R.hiz[0], R.hiz[1], R.hiz[2], R.hiz[3]};
+  const int4 cc = {R.c[0], R.c[1], R.c[2], R.c[3]};
+  node_step(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride, T.mode == MODE_SHADOW_ANY && T.unordered);
+}
+
+// The walk itself, from (cur, sp): ONE inlined copy per traversal (the op loop sets the walk up per lane and all walks of a
+// program — mesh or analytic, kernel-argument root or not — run through this loop).  `mesh` is uniform across the wave (it comes
+// from the program op): leaves hold triangles of the packed arrays (object-space ray `o`) or name one analytic primitive.
+template <int FEAT>
+__device__ __forceinline__ void walk_loop(const DScene& S, const bool mesh, int cur, int sp, const Frame32& F, const Ray& world, const Ray& o, Trav& T, Counters& C,
+                                          int* __restrict__ stack, int stride) {
   const int END = RTC_WALK_END;
   const bool any_hit = T.mode == MODE_SHADOW_ANY && T.unordered;  // wavefront shadow role only: 3 % there, -2 % in the one-kernel path
-  int sp = 0;
-  int cur = root;
-#ifdef RTC_NO_KROOT
-  kroot = nullptr;
-#endif
-  if (kroot) {  // every lane starts at the root: its boxes come from the kernel arguments
-    C.accel_nodes++;
-    C.knodes++;
-    float lo, hi;
-    t_interval32(T, lo, hi);
-    const float4 lox = {kroot->lox[0], kroot->lox[1], kroot->lox[2], kroot->lox[3]}, loy = {kroot->loy[0], kroot->loy[1], kroot->loy[2], kroot->loy[3]};
-    const float4 loz = {kroot->loz[0], kroot->loz[1], kroot->loz[2], kroot->loz[3]}, hix = {kroot->hix[0], kroot->hix[1], kroot->hix[2], kroot->hix[3]};
-    const float4 hiy = {kroot->hiy[0], kroot->hiy[1], kroot->hiy[2], kroot->hiy[3]}, hiz = {kroot->hiz[0], kroot->hiz[1], kroot->hiz[2], kroot->hiz[3]};
-    const int4 cc = {kroot->c[0], kroot->c[1], kroot->c[2], kroot->c[3]};
-    node_step(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride, any_hit);
-  }
+  float lo, hi;  // the pass's t interval in f32 (widened): only a leaf test can change it
+  t_interval32(T, lo, hi);
   for (;;) {
     DIAG_LOOP(0);
     // "while-while": descend through inner nodes until this lane holds a leaf (or has drained its stack); lanes that
@@ -525,8 +532,6 @@ __device__ __forceinline__ void bvh_walk(const DScene& S, int root, int frame, c
       DIAG_LOOP(3);
       const DBvhNode4* N = S.bvh + cur;
       C.accel_nodes++;
-      float lo, hi;
-      t_interval32(T, lo, hi);
       // the node's seven 16-byte rows: one line, all loads in flight together
       const float4 lox = ld4(N->lox), loy = ld4(N->loy), loz = ld4(N->loz), hix = ld4(N->hix), hiy = ld4(N->hiy), hiz = ld4(N->hiz);
       const int4 cc = ld4(N->c);
@@ -536,7 +541,7 @@ __device__ __forceinline__ void bvh_walk(const DScene& S, int root, int frame, c
     {
       DIAG_SPAN_BEGIN();
       int first = (~cur) >> 3, cnt = ((~cur) & 7) + 1;
-      if (MESH) {
+      if (mesh) {
         for (int i = first; i < first + cnt; i++) {
           DIAG_LOOP(1);
           double t, u, v;
@@ -549,6 +554,7 @@ __device__ __forceinline__ void bvh_walk(const DScene& S, int root, int frame, c
       }
       DIAG_SPAN_END(6);
       if (T.mode == MODE_SHADOW_ANY && T.shadowed) return;
+      if (T.mode != MODE_SHADOW_ANY && T.mode != MODE_CONTAINERS) t_interval32(T, lo, hi);  // closest passes: best_t may have come down
     }
     if (sp == 0) return;
     sp--;
@@ -630,23 +636,32 @@ __device__ __noinline__ int csg_eval(const DScene& S, int pc, const Ray& r, Trav
 }
 
 // World::intersect (src/world.rs:18-24) + Group::intersect (src/shape.rs:248-269) over the flattened program.
-// CSGK: the kernel instantiation for scenes that contain CSG groups; all others never see the (register-hungry) call.
-template <int FEAT>
+// KOPS: the program is the short jump-free one of the kernel arguments (DScene.kops: pc is wave-uniform, the op and the plane
+// records are scalar loads); else the program array in memory (any length, OP_GROUP jumps, per-primitive gates, CSG).  A kernel
+// instantiation has exactly one of the two, and each has exactly ONE inlined copy of the BVH walk.
+// MODE (optional): the pass kind as a compile-time constant (the caller set T.mode to it); -1 = read T.mode at run time.
+template <int FEAT, bool KOPS, int MODE = -1>
 __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T, Counters& C, int* __restrict__ stack, int stride) {
-  if (FEAT <= 1 && S.n_kops > 0) {
-    // short jump-free program from the kernel arguments: pc is wave-uniform, the op and the plane records are scalar loads
+  if (MODE >= 0) T.mode = MODE;
+  if (KOPS) {
     for (int pc = 0; pc < S.n_kops; pc++) {
       DIAG_LOOP(2);
       const DOp op = S.kops[pc];
+      bool walk = false;
+      const bool mesh = op.op == OP_MESH;
+      int cur = 0, sp = 0;
+      Frame32 F;
+      Ray o = r;
       if (op.op == OP_PRIM) {
         if (op.c >= 0) {
           // Plane (src/shape.rs:621-633): the same row-1 evaluation as visit_prim's plane case, operands from kernargs
           const DPlaneK P = S.kplanes[op.c];
           C.analytic_tests++;
           C.kplanes++;
+          DIAG_LOOP(8);
           double oy = P.row[0] * r.ox + P.row[1] * r.oy + P.row[2] * r.oz + P.row[3] * 1.0;
           double dy = P.row[0] * r.dx + P.row[1] * r.dy + P.row[2] * r.dz + P.row[3] * 0.0;
-          if (!(fabs(dy - 0.0) < EPS)) {
+          if (!(fabs(dy - 0.0) < EPS) && !plane_behind(T, oy, dy)) {
             double t = -oy / dy;
             accept(T, C, P.prim, 1, &t);
           }
@@ -659,21 +674,23 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
         DIAG_SPAN_BEGIN();
         quirk_grid_scan<FEAT>(S, op.pad[0] >= 0 ? S.kqgrid : S.qgrids[op.a], r, T, C);
         DIAG_SPAN_END(4);
-      } else if (op.op == OP_MESH) {
-        if (FEAT == 0 || op.g < 0 || groups_pass<false>(S, op.g, r, T, C)) {
-          if (op.pad[0] >= 0) {
-            const DKAux& A = S.kaux[op.pad[0]];
-            Ray o = to_object(A.xf, r);
-            bvh_walk<true, FEAT>(S, op.a, op.c, r, o, T, C, stack, stride, &A.root, A.frame);
-          } else {
-            Ray o = to_object(S.xf_inv + 12 * op.b, r);
-            bvh_walk<true, FEAT>(S, op.a, op.c, r, o, T, C, stack, stride);
-          }
+      } else if (!mesh || FEAT == 0 || op.g < 0 || groups_pass<false>(S, op.g, r, T, C)) {  // OP_MESH / OP_BVH
+        walk = true;
+        cur = op.a;
+        DIAG_LOOP(16);
+        if (op.pad[0] >= 0) {
+          const DKAux& A = S.kaux[op.pad[0]];
+          if (mesh) o = to_object(A.xf, r);
+          make_frame(A.frame, o, F);
+#ifndef RTC_NO_KROOT
+          walk_root_k(A.root, F, T, C, cur, sp, stack, stride);
+#endif
+        } else {
+          if (mesh) o = to_object(S.xf_inv + 12 * op.b, r);
+          make_frame(S.bvh_frame + 4 * op.c, o, F);
         }
-      } else {
-        if (op.pad[0] >= 0) bvh_walk<false, FEAT>(S, op.a, op.c, r, r, T, C, stack, stride, &S.kaux[op.pad[0]].root, S.kaux[op.pad[0]].frame);
-        else bvh_walk<false, FEAT>(S, op.a, op.c, r, r, T, C, stack, stride);
       }
+      if (walk) walk_loop<FEAT>(S, mesh, cur, sp, F, r, o, T, C, stack, stride);
       if (T.mode == MODE_SHADOW_ANY && T.shadowed) return;
     }
     return;
@@ -683,6 +700,9 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
   while (pc < n) {
     DIAG_LOOP(2);
     DOp op = S.ops[pc];
+    bool walk = false, mesh = false;
+    Frame32 F;
+    Ray o = r;
     if (op.op == OP_PRIM) {
       visit_prim<FEAT>(S, op.a, r, T, C, 0);
       pc++;
@@ -700,16 +720,16 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
     } else if (FEAT >= 3 && op.op == OP_CSG) {
       if (op.g >= 0 && !groups_pass(S, op.g, r, T, C)) pc = op.b + 1;
       else pc = csg_eval(S, pc, r, T, C);
-    } else if (op.op == OP_MESH) {
-      if (FEAT == 0 || op.g < 0 || groups_pass<(FEAT >= 2)>(S, op.g, r, T, C)) {
-        Ray o = to_object(S.xf_inv + 12 * op.b, r);
-        bvh_walk<true, FEAT>(S, op.a, op.c, r, o, T, C, stack, stride);
+    } else {  // OP_MESH / OP_BVH
+      mesh = op.op == OP_MESH;
+      if (!mesh || FEAT == 0 || op.g < 0 || groups_pass<(FEAT >= 2)>(S, op.g, r, T, C)) {
+        walk = true;
+        if (mesh) o = to_object(S.xf_inv + 12 * op.b, r);
+        make_frame(S.bvh_frame + 4 * op.c, o, F);
       }
       pc++;
-    } else {
-      bvh_walk<false, FEAT>(S, op.a, op.c, r, r, T, C, stack, stride);
-      pc++;
     }
+    if (walk) walk_loop<FEAT>(S, mesh, op.a, 0, F, r, o, T, C, stack, stride);
     if (T.mode == MODE_SHADOW_ANY && T.shadowed) return;
   }
 }
@@ -1087,7 +1107,7 @@ __device__ __forceinline__ Ray slot_ray(const DPixelMap& pm, const DCamera& cam,
 // One-kernel path: one lane walks one pixel's whole ray tree (closest pass, shading, shadow passes, pending children); the wave
 // ends with its slowest pixel.  (A persistent variant whose lanes took the next work id from a global counter was measured at
 // -4 % / +14 % and removed in round 2.)
-template <bool COUNT, int FEAT>
+template <bool COUNT, int FEAT, bool KOPS>
 __global__ void __launch_bounds__(RTC_BLOCK, (FEAT >= 2 && RTC_WAVES_PER_SIMD < 2) ? 2 : RTC_WAVES_PER_SIMD) rtc_trace_kernel(DScene S, DCamera cam, DPixelMap pm, int fuel0, double* __restrict__ rgb, double* __restrict__ hit_t,
                                                         int* __restrict__ hit_prim, int* __restrict__ hit_k, DStats* __restrict__ stats) {
   RTC_LDS_STACK(lds_stack);
@@ -1097,7 +1117,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, (FEAT >= 2 && RTC_WAVES_PER_SIMD < 
   unsigned n_primary = 0, n_shadow = 0, n_reflect = 0, n_refract = 0, n_container = 0;
   const WorkMap wm = make_workmap(pm, cam);
 #ifdef RTC_DIAG
-  if (threadIdx.x < 32) s_diag[threadIdx.x] = 0ull;
+  if (threadIdx.x < 64) s_diag[threadIdx.x] = 0ull;
   __syncthreads();
   unsigned long long diag_t0_ = 0;
   const unsigned long long diag_k0 = __builtin_amdgcn_s_memtime();
@@ -1125,7 +1145,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, (FEAT >= 2 && RTC_WAVES_PER_SIMD < 
       DIAG_T0();
       Trav T;
       reset_closest(T, MODE_CLOSEST);
-      traverse<FEAT>(S, ray, T, C, stack, stride);
+      traverse<FEAT, KOPS, MODE_CLOSEST>(S, ray, T, C, stack, stride);
       DIAG_REGION(0);
       bool did_hit = T.best_prim != 0x7fffffff;
       if (first) {
@@ -1147,13 +1167,13 @@ __global__ void __launch_bounds__(RTC_BLOCK, (FEAT >= 2 && RTC_WAVES_PER_SIMD < 
 
         // n1 / n2 / reflectance are only consumed when the surface is transparent (src/world.rs:70-78, :110)
         double n1 = 1.0, n2 = 1.0;
-        if (transparency != 0.0) {
+        if (transparency != 0.0 && fuel > 0) {
           n_container++;
           Trav K = T;  // keeps the hit key (thi = best_t, best_prim, best_klast)
           K.mode = MODE_CONTAINERS;
           K.tlo = -DINF; K.thi = T.best_t;
           K.c1_prim = -1; K.c2_prim = -1; K.c1_t = 0.0; K.c2_t = 0.0;
-          traverse<FEAT>(S, ray, K, C, stack, stride);
+          traverse<FEAT, KOPS, MODE_CONTAINERS>(S, ray, K, C, stack, stride);
           if (K.c1_prim >= 0) n1 = S.mat[8 * S.prims[K.c1_prim].mat + 6];
           if (K.c2_prim >= 0) n2 = S.mat[8 * S.prims[K.c2_prim].mat + 6];
           DIAG_REGION(1);
@@ -1188,7 +1208,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, (FEAT >= 2 && RTC_WAVES_PER_SIMD < 
           reset_closest(Sh, S.all_cast_shadow ? MODE_SHADOW_ANY : MODE_SHADOW_CLOSEST);
           if (S.all_cast_shadow) Sh.thi = distance;
           DIAG_T0();
-          traverse<FEAT>(S, sray, Sh, C, stack, stride);
+          traverse<FEAT, KOPS>(S, sray, Sh, C, stack, stride);
           DIAG_REGION(3);
           bool shadowed;
           if (S.all_cast_shadow) shadowed = Sh.shadowed != 0;
@@ -1207,7 +1227,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, (FEAT >= 2 && RTC_WAVES_PER_SIMD < 
             double rfx = mlx - st.nx * d2, rfy = mly - st.ny * d2, rfz = mlz - st.nz * d2;
             double rde = rfx * st.ex + rfy * st.ey + rfz * st.ez;
             if (rde > 0.0) {
-              double f = pow(rde, shininess);
+              double f = rtc_pow(rde, shininess);
               pr = LG[0] * specular * f; pg = LG[1] * specular * f; pb = LG[2] * specular * f;
             }
           }
@@ -1273,7 +1293,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, (FEAT >= 2 && RTC_WAVES_PER_SIMD < 
   atomicAdd(&s_diag[14], __builtin_amdgcn_s_memtime() - diag_k0);
   atomicAdd(&s_diag[15], 1ull);
   __syncthreads();
-  if (threadIdx.x < 32 && s_diag[threadIdx.x]) atomicAdd(&stats->diag[threadIdx.x], s_diag[threadIdx.x]);
+  if (threadIdx.x < 64 && s_diag[threadIdx.x]) atomicAdd(&stats->diag[threadIdx.x], s_diag[threadIdx.x]);
 #endif
   if (COUNT || true) {
     // nan_ts must always be published (error reporting); the rest only in the counting variant
@@ -1321,19 +1341,16 @@ __device__ __forceinline__ Ray wf_load_ray(const DWave& W, int level, unsigned i
 }  // namespace
 
 // wf_ts work item of the trace role: ray i of `level` (closest hit, container pass for transparent hits).
-template <int FEAT>
+template <int FEAT, bool KOPS>
 __device__ __forceinline__ void wf_trace_ray(const DScene& S, const DCamera& cam, const DPixelMap& pm, const DWave& W, const WorkMap& wm, int level, unsigned i,
                                              double* __restrict__ hit_t, int* __restrict__ hit_prim, int* __restrict__ hit_k, int* stack, int stride, Counters& C,
-                                             unsigned& n_rays, unsigned& n_container) {
+                                             unsigned& n_rays, unsigned& n_container, int fuel_left) {
   const size_t cap = W.cap;
-  double* cb = W.contrib + (size_t)level * 3 * cap;
   int32_t* ch = W.child + (size_t)level * 2 * cap;
-  cb[i] = 0.0; cb[cap + i] = 0.0; cb[2 * cap + i] = 0.0;
-  ch[i] = -1; ch[cap + i] = -1;
   Ray ray;
   uint64_t q = 0;
   if (level == 0) {
-    if (!work_to_slot(wm, i, q)) { W.h_prim[i] = -1; return; }
+    if (!work_to_slot(wm, i, q)) { W.h_prim[i] = -1; return; }  // tile padding: no pixel gathers this id
     ray = slot_ray(pm, cam, q);
   } else {
     double w_;
@@ -1342,7 +1359,7 @@ __device__ __forceinline__ void wf_trace_ray(const DScene& S, const DCamera& cam
   n_rays++;
   Trav T;
   reset_closest(T, MODE_CLOSEST);
-  traverse<FEAT>(S, ray, T, C, stack, stride);
+  traverse<FEAT, KOPS, MODE_CLOSEST>(S, ray, T, C, stack, stride);
   const bool did_hit = T.best_prim != 0x7fffffff;
   if (level == 0 && hit_t) {
     hit_t[q] = did_hit ? T.best_t : 0.0;
@@ -1350,29 +1367,33 @@ __device__ __forceinline__ void wf_trace_ray(const DScene& S, const DCamera& cam
     hit_k[q] = did_hit ? T.best_k : 0;
   }
   W.h_prim[i] = did_hit ? T.best_prim : -1;
+  // child links: none yet; a miss is marked as such (the gather then knows that no contribution was written for this ray)
+  ch[i] = did_hit ? -1 : RTC_WF_MISS; ch[cap + i] = -1;
   if (!did_hit) return;
   W.h_t[i] = T.best_t;
-  // n1 / n2 are only consumed when the surface is transparent (src/world.rs:70-78, :110)
-  double n1 = 1.0, n2 = 1.0;
-  if (S.mat[8 * S.prims[T.best_prim].mat + 5] != 0.0) {
+  // n1 / n2 are only consumed — and only stored — when the surface is transparent and the hit can still spawn rays
+  // (src/world.rs:70-78, :110); wf_shade reads them under the same condition
+  if (fuel_left > 0 && S.mat[8 * S.prims[T.best_prim].mat + 5] != 0.0) {
+    double n1 = 1.0, n2 = 1.0;
     n_container++;
     Trav K = T;  // keeps the hit key (thi = best_t, best_prim, best_klast)
     K.mode = MODE_CONTAINERS;
     K.tlo = -DINF; K.thi = T.best_t;
     K.c1_prim = -1; K.c2_prim = -1; K.c1_t = 0.0; K.c2_t = 0.0;
-    traverse<FEAT>(S, ray, K, C, stack, stride);
+    traverse<FEAT, KOPS, MODE_CONTAINERS>(S, ray, K, C, stack, stride);
     if (K.c1_prim >= 0) n1 = S.mat[8 * S.prims[K.c1_prim].mat + 6];
     if (K.c2_prim >= 0) n2 = S.mat[8 * S.prims[K.c2_prim].mat + 6];
+    W.h_n12[i] = n1; W.h_n12[cap + i] = n2;
   }
-  W.h_n12[i] = n1; W.h_n12[cap + i] = n2;
 }
 
 // wf_ts work item of the shadow role: shade record s of `level` (per light: shadow ray, then the Phong terms).
-template <int FEAT>
-__device__ __forceinline__ void wf_shadow_rec(const DScene& S, const DWave& W, int level, unsigned s, int* stack, int stride, Counters& C, unsigned& n_shadow) {
+template <int FEAT, bool KOPS>
+__device__ __forceinline__ void wf_shadow_rec(const DScene& S, const DCamera& cam, const DPixelMap& pm, const DWave& W, const WorkMap& wm, int level, unsigned s, int* stack,
+                                              int stride, Counters& C, unsigned& n_shadow) {
   const size_t cap = W.cap;
   double* cb = W.contrib + (size_t)level * 3 * cap;
-  const double* r = W.sr[level & 1];
+  const double* r = W.sr;
   const double px = r[s], py = r[cap + s], pz = r[2 * cap + s];
   // World::shade_hit (src/world.rs:50-82): per light, shadow test + Phong (src/shape.rs:429-462).  First every shadow
   // ray (only the point is live across the traversals), then the Phong terms with the rest of the record.
@@ -1388,16 +1409,29 @@ __device__ __forceinline__ void wf_shadow_rec(const DScene& S, const DWave& W, i
     Trav Sh;
     reset_closest(Sh, S.all_cast_shadow ? MODE_SHADOW_ANY : MODE_SHADOW_CLOSEST);
     if (S.all_cast_shadow) { Sh.thi = distance; Sh.unordered = 1; }
-    traverse<FEAT>(S, sray, Sh, C, stack, stride);
+    if (S.all_cast_shadow) traverse<FEAT, KOPS, MODE_SHADOW_ANY>(S, sray, Sh, C, stack, stride);  // mode: a compile-time constant in each
+    else traverse<FEAT, KOPS, MODE_SHADOW_CLOSEST>(S, sray, Sh, C, stack, stride);
     bool shadowed;
     if (S.all_cast_shadow) shadowed = Sh.shadowed != 0;
     else shadowed = (Sh.best_prim != 0x7fffffff) && (S.prims[Sh.best_prim].flags & 1u) && (Sh.best_t < distance);
     if (shadowed) shadow_mask |= 1ull << l;
   }
-  const double ex = r[3 * cap + s], ey = r[4 * cap + s], ez = r[5 * cap + s];
-  const double nx = r[6 * cap + s], ny = r[7 * cap + s], nz = r[8 * cap + s];
-  const double cr = r[9 * cap + s], cg = r[10 * cap + s], cbl = r[11 * cap + s];
-  const double* M = S.mat + 8 * W.sr_mat[level & 1][s];
+  const double nx = r[3 * cap + s], ny = r[4 * cap + s], nz = r[5 * cap + s];
+  const double cr = r[6 * cap + s], cg = r[7 * cap + s], cbl = r[8 * cap + s];
+  // the eye vector (= -direction, src/intersection.rs:56) and the path weight of the ray come from where the ray itself came
+  // from: the level's queue (still intact: the next shading kernel is the first to overwrite it) or, at level 0, the camera
+  const int node = W.sr_node[s];
+  double ex, ey, ez, weight;
+  if (level == 0) {
+    uint64_t q = 0;
+    (void)work_to_slot(wm, (unsigned)node, q);
+    const Ray pr = slot_ray(pm, cam, q);
+    ex = -pr.dx; ey = -pr.dy; ez = -pr.dz; weight = 1.0;
+  } else {
+    const double* rq = W.rq[level & 1];
+    ex = -rq[3 * cap + node]; ey = -rq[4 * cap + node]; ez = -rq[5 * cap + node]; weight = rq[6 * cap + node];
+  }
+  const double* M = S.mat + 8 * W.sr_mat[s];
   const double ambient = M[0], diffuse = M[1], specular = M[2], shininess = M[3];
   double sr = 0.0, sg = 0.0, sb = 0.0;
   for (int l = 0; l < S.n_lights; l++) {
@@ -1419,14 +1453,12 @@ __device__ __forceinline__ void wf_shadow_rec(const DScene& S, const DWave& W, i
       double rfx = mlx - nx * d2, rfy = mly - ny * d2, rfz = mlz - nz * d2;
       double rde = rfx * ex + rfy * ey + rfz * ez;
       if (rde > 0.0) {
-        double f = pow(rde, shininess);
+        double f = rtc_pow(rde, shininess);
         pr = LG[0] * specular * f; pg = LG[1] * specular * f; pb = LG[2] * specular * f;
       }
     }
     sr += (lr + dr) + pr; sg += (lg + dg) + pg; sb += (lb + db) + pb;
   }
-  const double weight = r[12 * cap + s];
-  const int node = W.sr_node[level & 1][s];
   cb[node] = weight * sr; cb[cap + node] = weight * sg; cb[2 * cap + node] = weight * sb;
 }
 
@@ -1434,9 +1466,13 @@ __device__ __forceinline__ void wf_shadow_rec(const DScene& S, const DWave& W, i
 // (either may be -1) as ONE launch, so the two independent passes fill the chip together.  Work is handed out in chunks of
 // RTC_WF_CHUNK items from per-XCD counters (block b belongs to XCD b % 8 and takes chunks b % 8, b % 8 + 8, ...): trace
 // chunks first (the next shading kernel waits for them), then shadow chunks; a wave that finishes early simply takes more.
-template <bool COUNT, int FEAT>
-__global__ void __launch_bounds__(RTC_BLOCK, FEAT <= 1 ? 4 : 2) wf_ts(DScene S, DCamera cam, DPixelMap pm, DWave W, int tl, int sl, unsigned n0, int slot, double* __restrict__ hit_t,
-                                                                     int* __restrict__ hit_prim, int* __restrict__ hit_k, DStats* __restrict__ stats) {
+#ifndef RTC_WF_TS_WAVES
+#define RTC_WF_TS_WAVES 3  // waves per SIMD the traversal kernel is compiled for: 168 VGPRs, no scratch.  At 4 (128 VGPRs) the ray and the
+                           // leaf record spill around every leaf test: same frame time, +1.7 GB of HBM traffic per frame (profiles/r2_*)
+#endif
+template <bool COUNT, int FEAT, bool KOPS>
+__global__ void __launch_bounds__(RTC_BLOCK, FEAT <= 1 ? RTC_WF_TS_WAVES : 2) wf_ts(DScene S, DCamera cam, DPixelMap pm, DWave W, int tl, int sl, unsigned n0, int slot, int fuel_left,
+                                                                     double* __restrict__ hit_t, int* __restrict__ hit_prim, int* __restrict__ hit_k, DStats* __restrict__ stats) {
   RTC_LDS_STACK(lds_stack);
   int* stack = lds_stack + threadIdx.x;
   const int stride = RTC_BLOCK;
@@ -1461,13 +1497,13 @@ __global__ void __launch_bounds__(RTC_BLOCK, FEAT <= 1 ? 4 : 2) wf_ts(DScene S, 
       const unsigned base = (unsigned)chunk * RTC_WF_CHUNK;
       for (unsigned o = 0; o < RTC_WF_CHUNK; o += RTC_WF_LANES) {
         const unsigned i = base + o + (unsigned)lane;
-        if (i < nt) wf_trace_ray<FEAT>(S, cam, pm, W, wm, tl, i, hit_t, hit_prim, hit_k, stack, stride, C, n_rays, n_container);
+        if (i < nt) wf_trace_ray<FEAT, KOPS>(S, cam, pm, W, wm, tl, i, hit_t, hit_prim, hit_k, stack, stride, C, n_rays, n_container, fuel_left);
       }
     } else {
       const unsigned base = (unsigned)(chunk - ct) * RTC_WF_CHUNK;
       for (unsigned o = 0; o < RTC_WF_CHUNK; o += RTC_WF_LANES) {
         const unsigned s = base + o + (unsigned)lane;
-        if (s < ns) wf_shadow_rec<FEAT>(S, W, sl, s, stack, stride, C, n_shadow);
+        if (s < ns) wf_shadow_rec<FEAT, KOPS>(S, cam, pm, W, wm, sl, s, stack, stride, C, n_shadow);
       }
     }
   }

@@ -1,24 +1,57 @@
-// rtc_feat.hip — the ray kernels of ONE feature level (compiled once per level with -DRTC_FEAT=0..3, in parallel: each
-// instantiation of the traversal is ~40 k instructions and most of the library's build time).  Feature levels: rtc_device.hpp,
-// visit_prim.  Exports rtc_launch_trace_f<N> / rtc_launch_wf_ts_f<N> for the dispatchers in rtc_kernels.hip.
+// rtc_feat.hip — the ray kernels of ONE kernel variant (compiled once per variant with -DRTC_VARIANT=0..4, in parallel: each
+// instantiation of the traversal is tens of thousands of instructions and most of the library's build time).
+//   variant   feature level (rtc_device.hpp, visit_prim)          program
+//   0         0: no gates                                          kernel arguments (DScene.kops)
+//   1         1: whole meshes gated                                kernel arguments
+//   2         1 (also serves gate-free programs too long for the kernel arguments)   memory (DScene.ops)
+//   3         2: per-primitive gates                               memory
+//   4         3: + CSG                                             memory
+// Exports rtc_launch_trace_v<N> / rtc_launch_wf_ts_v<N> for the dispatchers in rtc_kernels.hip.
 #include "rtc_device.hpp"
 
-#ifndef RTC_FEAT
-#error "compile with -DRTC_FEAT=0..3"
+#ifndef RTC_VARIANT
+#error "compile with -DRTC_VARIANT=0..4"
 #endif
 #ifndef RTC_CAT
 #define RTC_CAT2(a, b) a##b
 #define RTC_CAT(a, b) RTC_CAT2(a, b)
 #endif
+#undef RTC_V_FEAT
+#undef RTC_V_KOPS
+#if RTC_VARIANT == 0
+#define RTC_V_FEAT 0
+#define RTC_V_KOPS true
+#elif RTC_VARIANT == 1
+#define RTC_V_FEAT 1
+#define RTC_V_KOPS true
+#elif RTC_VARIANT == 2
+#define RTC_V_FEAT 1
+#define RTC_V_KOPS false
+#elif RTC_VARIANT == 3
+#define RTC_V_FEAT 2
+#define RTC_V_KOPS false
+#else
+#define RTC_V_FEAT 3
+#define RTC_V_KOPS false
+#endif
 
-void RTC_CAT(rtc_launch_trace_f, RTC_FEAT)(bool count, unsigned grid, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb,
-                                           double* hit_t, int* hit_prim, int* hit_k, DStats* stats) {
-  if (count) hipLaunchKernelGGL((rtc_trace_kernel<true, RTC_FEAT>), dim3(grid), dim3(RTC_BLOCK), rtc_stack_bytes(S), stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats);
-  else hipLaunchKernelGGL((rtc_trace_kernel<false, RTC_FEAT>), dim3(grid), dim3(RTC_BLOCK), rtc_stack_bytes(S), stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats);
+void RTC_CAT(rtc_launch_trace_v, RTC_VARIANT)(bool count, unsigned grid, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb,
+                                              double* hit_t, int* hit_prim, int* hit_k, DStats* stats) {
+  if (count) hipLaunchKernelGGL((rtc_trace_kernel<true, RTC_V_FEAT, RTC_V_KOPS>), dim3(grid), dim3(RTC_BLOCK), rtc_stack_bytes(S), stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats);
+  else hipLaunchKernelGGL((rtc_trace_kernel<false, RTC_V_FEAT, RTC_V_KOPS>), dim3(grid), dim3(RTC_BLOCK), rtc_stack_bytes(S), stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats);
 }
 
-void RTC_CAT(rtc_launch_wf_ts_f, RTC_FEAT)(bool count, unsigned grid, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, const DWave& W, int tl, int sl,
-                                           unsigned n0, int slot, double* hit_t, int* hit_prim, int* hit_k, DStats* stats) {
-  if (count) hipLaunchKernelGGL((wf_ts<true, RTC_FEAT>), dim3(grid), dim3(RTC_BLOCK), rtc_stack_bytes(S), stream, S, cam, pm, W, tl, sl, n0, slot, hit_t, hit_prim, hit_k, stats);
-  else hipLaunchKernelGGL((wf_ts<false, RTC_FEAT>), dim3(grid), dim3(RTC_BLOCK), rtc_stack_bytes(S), stream, S, cam, pm, W, tl, sl, n0, slot, hit_t, hit_prim, hit_k, stats);
+void RTC_CAT(rtc_launch_wf_ts_v, RTC_VARIANT)(bool count, unsigned grid, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, const DWave& W, int tl, int sl,
+                                              unsigned n0, int slot, int fuel_left, double* hit_t, int* hit_prim, int* hit_k, DStats* stats) {
+  if (count) hipLaunchKernelGGL((wf_ts<true, RTC_V_FEAT, RTC_V_KOPS>), dim3(grid), dim3(RTC_BLOCK), rtc_stack_bytes(S), stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
+  else hipLaunchKernelGGL((wf_ts<false, RTC_V_FEAT, RTC_V_KOPS>), dim3(grid), dim3(RTC_BLOCK), rtc_stack_bytes(S), stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
 }
+
+#ifndef RTC_EMU
+// resident waves per CU of this variant's traversal kernel (the persistent grid of the wavefront path)
+int RTC_CAT(rtc_wf_ts_blocks_per_cu_v, RTC_VARIANT)(unsigned lds_bytes) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wf_ts<false, RTC_V_FEAT, RTC_V_KOPS>, RTC_BLOCK, lds_bytes) != hipSuccess || nb <= 0) nb = 8;
+  return nb;
+}
+#endif

@@ -3,31 +3,39 @@
 // templates in rtc_device.hpp, instantiated per feature level by rtc_feat.hip (one translation unit per level, built in parallel).
 #include "rtc_device.hpp"
 
-#define RTC_FEAT_DECL(N)                                                                                                                                      \
-  void rtc_launch_trace_f##N(bool count, unsigned grid, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, \
+#define RTC_VARIANT_DECL(N)                                                                                                                                   \
+  void rtc_launch_trace_v##N(bool count, unsigned grid, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, \
                              double* hit_t, int* hit_prim, int* hit_k, DStats* stats);                                                                       \
-  void rtc_launch_wf_ts_f##N(bool count, unsigned grid, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, const DWave& W, int tl, \
-                             int sl, unsigned n0, int slot, double* hit_t, int* hit_prim, int* hit_k, DStats* stats);
-RTC_FEAT_DECL(0) RTC_FEAT_DECL(1) RTC_FEAT_DECL(2) RTC_FEAT_DECL(3)
-#undef RTC_FEAT_DECL
+  void rtc_launch_wf_ts_v##N(bool count, unsigned grid, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, const DWave& W, int tl, \
+                             int sl, unsigned n0, int slot, int fuel_left, double* hit_t, int* hit_prim, int* hit_k, DStats* stats);                         \
+  int rtc_wf_ts_blocks_per_cu_v##N(unsigned lds_bytes);
+RTC_VARIANT_DECL(0) RTC_VARIANT_DECL(1) RTC_VARIANT_DECL(2) RTC_VARIANT_DECL(3) RTC_VARIANT_DECL(4)
+#undef RTC_VARIANT_DECL
 #ifdef RTC_EMU
 // the CPU emulator (tests/cpu_emu) compiles everything as one translation unit
-#define RTC_FEAT 0
+#define RTC_VARIANT 0
 #include "rtc_feat.hip"
-#undef RTC_FEAT
-#define RTC_FEAT 1
+#undef RTC_VARIANT
+#define RTC_VARIANT 1
 #include "rtc_feat.hip"
-#undef RTC_FEAT
-#define RTC_FEAT 2
+#undef RTC_VARIANT
+#define RTC_VARIANT 2
 #include "rtc_feat.hip"
-#undef RTC_FEAT
-#define RTC_FEAT 3
+#undef RTC_VARIANT
+#define RTC_VARIANT 3
 #include "rtc_feat.hip"
-#undef RTC_FEAT
+#undef RTC_VARIANT
+#define RTC_VARIANT 4
+#include "rtc_feat.hip"
+#undef RTC_VARIANT
 #endif
 
-// feature level of the kernel instantiation a scene needs (rtc_device.hpp, visit_prim)
-static int rtc_feature_level(const DScene& S) { return S.has_csg ? 3 : (S.has_groups == 2 ? 2 : (S.has_groups ? 1 : 0)); }
+// kernel variant a scene needs (rtc_feat.hip): its feature level (rtc_device.hpp, visit_prim) and where its program lives
+static int rtc_variant(const DScene& S) {
+  const int feat = S.has_csg ? 3 : (S.has_groups == 2 ? 2 : (S.has_groups ? 1 : 0));
+  if (feat <= 1 && S.n_kops > 0) return feat;
+  return feat <= 1 ? 2 : feat + 1;
+}
 
 #ifndef RTC_WF_SHADE_WAVES
 #define RTC_WF_SHADE_WAVES 4  // <= 128 VGPRs: two 512-thread blocks per CU, so one block's wait for its queue atomics is covered by the other
@@ -73,7 +81,7 @@ __global__ void __launch_bounds__(RTC_WF_SHADE_BLOCK, RTC_WF_SHADE_WAVES) wf_sha
       double hu, hv;
       hit_uv(S, P, ray, hu, hv);
       prepare_state(S, P, ray, W.h_t[i], hu, hv, st);
-      n1 = W.h_n12[i]; n2 = W.h_n12[cap + i];
+      if (transparency != 0.0 && fuel > 0) { n1 = W.h_n12[i]; n2 = W.h_n12[cap + i]; }  // stored under the same condition
       // Pattern::color_at(material_inv * over_point) — identical for every light (src/shape.rs:437)
       const double* mi = S.xf_matinv + 16 * P.xform;
       double x = mi[0] * st.px + mi[1] * st.py + mi[2] * st.pz + mi[3] * 1.0;
@@ -134,14 +142,12 @@ __global__ void __launch_bounds__(RTC_WF_SHADE_BLOCK, RTC_WF_SHADE_WAVES) wf_sha
     const unsigned jr = s_child[wave] + (unsigned)__popcll(m_refl & lt);
     const unsigned jt = s_child[wave] + (unsigned)__popcll(m_refl) + (unsigned)__popcll(m_refr & lt);
     if (hit && s < W.cap) {
-      double* r = W.sr[level & 1];
+      double* r = W.sr;
       r[s] = st.px; r[cap + s] = st.py; r[2 * cap + s] = st.pz;
-      r[3 * cap + s] = st.ex; r[4 * cap + s] = st.ey; r[5 * cap + s] = st.ez;
-      r[6 * cap + s] = st.nx; r[7 * cap + s] = st.ny; r[8 * cap + s] = st.nz;
-      r[9 * cap + s] = cr; r[10 * cap + s] = cg; r[11 * cap + s] = cbl;
-      r[12 * cap + s] = weight;
-      W.sr_mat[level & 1][s] = mat;
-      W.sr_node[level & 1][s] = (int32_t)i;
+      r[3 * cap + s] = st.nx; r[4 * cap + s] = st.ny; r[5 * cap + s] = st.nz;
+      r[6 * cap + s] = cr; r[7 * cap + s] = cg; r[8 * cap + s] = cbl;
+      W.sr_mat[s] = mat;
+      W.sr_node[s] = (int32_t)i;
     }
     if (do_refl && jr < W.cap) {
       nq[jr] = st.px; nq[cap + jr] = st.py; nq[2 * cap + jr] = st.pz; nq[3 * cap + jr] = st.rx; nq[4 * cap + jr] = st.ry; nq[5 * cap + jr] = st.rz;
@@ -178,8 +184,8 @@ __global__ void __launch_bounds__(256) wf_gather(DCamera cam, DPixelMap pm, DWav
     for (;;) {
       const double* cb = W.contrib + (size_t)lvl * 3 * cap;
       const int32_t* ch = W.child + (size_t)lvl * 2 * cap;
-      r += cb[idx]; g += cb[cap + idx]; b += cb[2 * cap + idx];
       const int a = ch[idx], c = ch[cap + idx];
+      if (a != RTC_WF_MISS) { r += cb[idx]; g += cb[cap + idx]; b += cb[2 * cap + idx]; }  // a miss wrote no contribution
       if (c >= 0) { wait_idx[sp] = c; wait_lvl[sp] = lvl + 1; sp++; }
       if (a >= 0) { idx = a; lvl++; continue; }
       if (sp == 0) break;
@@ -191,13 +197,33 @@ __global__ void __launch_bounds__(256) wf_gather(DCamera cam, DPixelMap pm, DWav
 }
 
 
-static void launch_wf_ts(int feat, bool count, unsigned grid, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, const DWave& W, int tl, int sl,
-                         unsigned n0, int slot, double* hit_t, int* hit_prim, int* hit_k, DStats* stats) {
-  if (feat >= 3) rtc_launch_wf_ts_f3(count, grid, stream, S, cam, pm, W, tl, sl, n0, slot, hit_t, hit_prim, hit_k, stats);
-  else if (feat == 2) rtc_launch_wf_ts_f2(count, grid, stream, S, cam, pm, W, tl, sl, n0, slot, hit_t, hit_prim, hit_k, stats);
-  else if (feat == 1) rtc_launch_wf_ts_f1(count, grid, stream, S, cam, pm, W, tl, sl, n0, slot, hit_t, hit_prim, hit_k, stats);
-  else rtc_launch_wf_ts_f0(count, grid, stream, S, cam, pm, W, tl, sl, n0, slot, hit_t, hit_prim, hit_k, stats);
+static void launch_wf_ts(int v, bool count, unsigned grid, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, const DWave& W, int tl, int sl,
+                         unsigned n0, int slot, int fuel_left, double* hit_t, int* hit_prim, int* hit_k, DStats* stats) {
+  switch (v) {
+    case 0: rtc_launch_wf_ts_v0(count, grid, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats); break;
+    case 1: rtc_launch_wf_ts_v1(count, grid, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats); break;
+    case 2: rtc_launch_wf_ts_v2(count, grid, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats); break;
+    case 3: rtc_launch_wf_ts_v3(count, grid, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats); break;
+    default: rtc_launch_wf_ts_v4(count, grid, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats); break;
+  }
 }
+
+#ifndef RTC_EMU
+// Grid of the wavefront traversal kernel: as many one-wave blocks as the chip holds at once (the kernel hands out chunks
+// itself), from the occupancy the runtime reports for this scene's variant and LDS stack size.
+unsigned rtc_wavefront_grid(const DScene& S, int n_cu) {
+  const unsigned lds = rtc_stack_bytes(S);
+  int per_cu = 8;
+  switch (rtc_variant(S)) {
+    case 0: per_cu = rtc_wf_ts_blocks_per_cu_v0(lds); break;
+    case 1: per_cu = rtc_wf_ts_blocks_per_cu_v1(lds); break;
+    case 2: per_cu = rtc_wf_ts_blocks_per_cu_v2(lds); break;
+    case 3: per_cu = rtc_wf_ts_blocks_per_cu_v3(lds); break;
+    default: per_cu = rtc_wf_ts_blocks_per_cu_v4(lds); break;
+  }
+  return (unsigned)std::max(1, n_cu * per_cu);
+}
+#endif
 
 // work ids of a launch (tile padding included): the minimum DWave.cap
 uint64_t rtc_wavefront_work(const DCamera& cam, const DPixelMap& pm) {
@@ -206,17 +232,18 @@ uint64_t rtc_wavefront_work(const DCamera& cam, const DPixelMap& pm) {
 }
 
 // One frame through the wavefront kernels.  The caller zeroed W.counts (RTC_WF_COUNTS entries) on the stream and sized the
-// arrays for W.cap >= the work ids of the launch and fuel + 1 levels; `blocks` = grid size of the traversal kernels.
+// arrays for W.cap >= the work ids of the launch and fuel + 1 levels; `blocks` / `shade_blocks` = grid sizes of the traversal /
+// shading kernels.
 void rtc_launch_wavefront(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, const DWave& W, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
-                          DStats* stats, bool count, hipStream_t stream, unsigned blocks) {
+                          DStats* stats, bool count, hipStream_t stream, unsigned blocks, unsigned shade_blocks) {
   if (pm.n == 0) return;
-  const int feat = rtc_feature_level(S);
+  const int v = rtc_variant(S);
   const unsigned n0 = (unsigned)rtc_wavefront_work(cam, pm);
-  const dim3 sgrid(std::max(1u, blocks * RTC_BLOCK / (unsigned)RTC_WF_SHADE_BLOCK / RTC_WF_SHADE_GRID_DIV)), sblock(RTC_WF_SHADE_BLOCK);
+  const dim3 sgrid(std::max(1u, shade_blocks)), sblock(RTC_WF_SHADE_BLOCK);
   // trace_0; shade_0; [shadow_0 + trace_1]; shade_1; ... [shadow_{fuel-1} + trace_fuel]; shade_fuel; shadow_fuel; sums
   for (int level = 0; level <= fuel + 1; level++) {
     const int tl = level <= fuel ? level : -1, sl = level - 1;
-    launch_wf_ts(feat, count, blocks, stream, S, cam, pm, W, tl, sl, n0, level, hit_t, hit_prim, hit_k, stats);
+    launch_wf_ts(v, count, blocks, stream, S, cam, pm, W, tl, sl, n0, level, fuel - level, hit_t, hit_prim, hit_k, stats);
     if (level <= fuel) {
       if (count) hipLaunchKernelGGL((wf_shade<true>), sgrid, sblock, 0, stream, S, cam, pm, W, level, n0, fuel, stats);
       else hipLaunchKernelGGL((wf_shade<false>), sgrid, sblock, 0, stream, S, cam, pm, W, level, n0, fuel, stats);
@@ -267,10 +294,12 @@ void rtc_launch_deinterleave(const double* slab, double* image, unsigned rowlen,
 void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
                       DStats* stats, bool count, hipStream_t stream) {
   if (pm.n == 0) return;
-  const int feat = rtc_feature_level(S);
   const unsigned grid = (unsigned)((rtc_wavefront_work(cam, pm) + RTC_BLOCK - 1) / RTC_BLOCK);
-  if (feat >= 3) rtc_launch_trace_f3(count, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats);
-  else if (feat == 2) rtc_launch_trace_f2(count, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats);
-  else if (feat == 1) rtc_launch_trace_f1(count, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats);
-  else rtc_launch_trace_f0(count, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats);
+  switch (rtc_variant(S)) {
+    case 0: rtc_launch_trace_v0(count, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats); break;
+    case 1: rtc_launch_trace_v1(count, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats); break;
+    case 2: rtc_launch_trace_v2(count, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats); break;
+    case 3: rtc_launch_trace_v3(count, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats); break;
+    default: rtc_launch_trace_v4(count, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats); break;
+  }
 }

@@ -21,8 +21,9 @@ void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, 
 void rtc_launch_quantize(const double* rgb, unsigned char* out, unsigned long long n, hipStream_t stream);
 void rtc_launch_deinterleave(const double* slab, double* image, unsigned rowlen, unsigned vsize, unsigned n, unsigned max_rows, hipStream_t stream);
 void rtc_launch_wavefront(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, const DWave& W, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
-                          DStats* stats, bool count, hipStream_t stream, unsigned blocks);
+                          DStats* stats, bool count, hipStream_t stream, unsigned blocks, unsigned shade_blocks);
 uint64_t rtc_wavefront_work(const DCamera& cam, const DPixelMap& pm);
+unsigned rtc_wavefront_grid(const DScene& S, int n_cu);
 
 static thread_local std::string g_rtc_err;
 static int rtc_fail(int code, const std::string& m) {
@@ -64,8 +65,8 @@ struct rtc_scene {
   void* wave_mem = nullptr;
   uint64_t wave_cap = 0;
   int wave_levels = 0;
-  unsigned wave_blocks = 0;
-  unsigned wave_mul = 2;  // queue capacity per level, in multiples of the launch's level-0 work ids
+  unsigned wave_blocks = 0, shade_blocks = 0;
+  unsigned wave_eighths = 9;  // queue capacity per level, in eighths of the launch's level-0 work ids
   int bvh_depth = 0;
   uint32_t n_bvh_nodes = 0, n_mesh_tris = 0;
 
@@ -99,19 +100,19 @@ int ensure_px(rtc_scene* s, uint64_t n, bool hits) {
   return RTC_OK;
 }
 
-// Sizes the wavefront arrays for `n_work` level-0 work ids and fuel + 1 levels: every level may hold up to wave_mul x n_work
-// rays (2 to start with).  A level that needs more sets the overflow flag; a synchronous launch then doubles wave_mul and
-// renders again while the arrays stay under RTC_WF_MAX_BYTES (default 24 GiB), else falls back to the one-kernel path.
-uint64_t wave_bytes(uint64_t cap, int lv) {
-  return cap * (uint64_t)(7 + 7 + 1 + 2 + 13 + 13 + 3 * lv) * sizeof(double) + (cap * (uint64_t)(1 + 2 + 2 + 2 * lv) + RTC_WF_COUNTS) * sizeof(int32_t);
-}
+// Sizes the wavefront arrays for `n_work` level-0 work ids and fuel + 1 levels: every level may hold up to wave_eighths / 8 x
+// n_work rays (1.125 x to start with: a level larger than the frame's work ids needs most hits to spawn two rays).  A level that
+// needs more sets the overflow flag; a synchronous launch then doubles the factor and renders again while the arrays stay
+// under RTC_WF_MAX_BYTES (default 24 GiB), else falls back to the one-kernel path.
+uint64_t wave_cap(const rtc_scene* s, uint64_t n_work, unsigned eighths) { (void)s; return std::max<uint64_t>((n_work * eighths + 7) / 8, 4096); }
+uint64_t wave_bytes(uint64_t cap, int lv) { return dwave_bytes(cap, lv); }
 uint64_t wave_budget() {
   const char* e = std::getenv("RTC_WF_MAX_BYTES");
   return e ? std::strtoull(e, nullptr, 10) : (24ull << 30);
 }
 int ensure_wave(rtc_scene* s, uint64_t n_work, int fuel) {
   const int levels = fuel + 1;
-  uint64_t cap = std::max<uint64_t>((uint64_t)s->wave_mul * n_work, 4096);
+  uint64_t cap = wave_cap(s, n_work, s->wave_eighths);
   if (cap > 0x7fffff00ull || wave_bytes(cap, levels) > wave_budget()) return rtc_fail(RTC_ERR_UNSUPPORTED, "launch too large for the wavefront path");
   if (cap <= s->wave_cap && levels <= s->wave_levels) return RTC_OK;
   cap = std::max(cap, s->wave_cap);
@@ -132,24 +133,7 @@ int ensure_wave(rtc_scene* s, uint64_t n_work, int fuel) {
       return rtc_fail(RTC_ERR_DEVICE, std::string("hipMalloc of the wavefront queues: ") + hipGetErrorString(e));
     }
   }
-  double* d = (double*)s->wave_mem;
-  DWave& W = s->wave;
-  W.rq[0] = d; d += 7 * cap;
-  W.rq[1] = d; d += 7 * cap;
-  W.h_t = d; d += cap;
-  W.h_n12 = d; d += 2 * cap;
-  W.sr[0] = d; d += 13 * cap;
-  W.sr[1] = d; d += 13 * cap;
-  W.contrib = d; d += 3 * (uint64_t)lv * cap;
-  int32_t* q = (int32_t*)d;
-  W.h_prim = q; q += cap;
-  W.sr_mat[0] = q; q += cap;
-  W.sr_mat[1] = q; q += cap;
-  W.sr_node[0] = q; q += cap;
-  W.sr_node[1] = q; q += cap;
-  W.child = q; q += 2 * (uint64_t)lv * cap;
-  W.counts = (uint32_t*)q;
-  W.cap = (uint32_t)cap;
+  dwave_carve(&s->wave, s->wave_mem, cap, lv);
   s->wave_cap = cap;
   s->wave_levels = lv;
   return RTC_OK;
@@ -218,7 +202,7 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
     if (rc != RTC_OK) return rc;
     HIP_OK(hipMemsetAsync(s->wave.counts, 0, RTC_WF_COUNTS * sizeof(uint32_t), s->stream));
     HIP_OK(hipEventRecord(s->ev0, s->stream));
-    rtc_launch_wavefront(s->d, cam, pm, fuel, s->wave, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream, s->wave_blocks);
+    rtc_launch_wavefront(s->d, cam, pm, fuel, s->wave, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream, s->wave_blocks, s->shade_blocks);
   } else {
     rtc_launch_trace(s->d, cam, pm, fuel, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream);
   }
@@ -230,12 +214,19 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
   int rcs = read_clear_sticky(s, &h);
   if (rcs != RTC_OK) return rcs;
   if (wavefront) {
+    if (std::getenv("RTC_WF_DUMP_COUNTS")) {  // debug aid: rays and shade records per level of this frame
+      uint32_t c[64];
+      HIP_OK(hipMemcpy(c, s->wave.counts, sizeof(c), hipMemcpyDeviceToHost));
+      std::fprintf(stderr, "[rtc-wf] level: rays / shade records:");
+      for (int l = 0; l <= fuel; l++) std::fprintf(stderr, " %d: %u / %u;", l, l ? c[l] : (unsigned)rtc_wavefront_work(cam, pm), c[RTC_WF_SHADE_COUNT + l]);
+      std::fprintf(stderr, "\n");
+    }
     uint32_t overflow = 0;
     HIP_OK(hipMemcpy(&overflow, s->wave.counts + RTC_WF_OVERFLOW, sizeof(overflow), hipMemcpyDeviceToHost));
     if (overflow) {  // a level outgrew its queue: larger queues if they fit the budget, else the one-kernel path (always fits)
       const uint64_t n_work = rtc_wavefront_work(cam, pm);
-      if (s->wave_mul < 64 && wave_bytes(2ull * s->wave_mul * n_work, fuel + 1) <= wave_budget() && 2ull * s->wave_mul * n_work <= 0x7fffff00ull) {
-        s->wave_mul *= 2;
+      if (s->wave_eighths < 512 && wave_bytes(wave_cap(s, n_work, 2 * s->wave_eighths), fuel + 1) <= wave_budget() && wave_cap(s, n_work, 2 * s->wave_eighths) <= 0x7fffff00ull) {
+        s->wave_eighths *= 2;
         const int rc2 = run(s, cam, pm, fuel, d_rgb, want_hits, stats, count, true, 4);
         if (rc2 != RTC_ERR_UNSUPPORTED) return rc2;  // (the larger queues were refused by the device: fall through)
       }
@@ -265,7 +256,7 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
   }
   if (std::getenv("RTC_DIAG_DUMP")) {  // RTC_DIAG builds: raw region / utilisation counters for scripts/diag_report.py
     std::fprintf(stderr, "[rtc-diag]");
-    for (int i = 0; i < 32; i++) std::fprintf(stderr, " %llu", (unsigned long long)h.diag[i]);
+    for (int i = 0; i < 64; i++) std::fprintf(stderr, " %llu", (unsigned long long)h.diag[i]);
     std::fprintf(stderr, "\n");
   }
   if (h.guard) return rtc_fail(RTC_ERR_DEVICE, "traversal guard tripped (mask " + std::to_string(h.guard) + "): an index left its array; no pixel since the last check is trustworthy");
@@ -366,8 +357,11 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     // this library may run on the HIP runtime PyTorch loaded first.
     int n_cu = 0;
     HIP_OK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device));
-    s->wave_blocks = (unsigned)std::max(1, n_cu * 32);
+    // traversal kernel: a persistent grid of one-wave blocks, as many as the chip holds; shading kernel: two 512-thread blocks per CU
+    s->wave_blocks = rtc_wavefront_grid(s->d, n_cu);
     if (const char* w = std::getenv("RTC_WF_BLOCKS_PER_CU")) s->wave_blocks = (unsigned)std::max(1, n_cu * std::atoi(w));
+    s->shade_blocks = (unsigned)std::max(1, n_cu * 2);
+    if (const char* w = std::getenv("RTC_WF_SHADE_BLOCKS_PER_CU")) s->shade_blocks = (unsigned)std::max(1, n_cu * std::atoi(w));
   }
   *out = s.release();
   return RTC_OK;

@@ -38,19 +38,14 @@ static int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double*
     const uint64_t n_work = rtc_wavefront_work(cam, pm);
     const int lv = fuel + 1;
     bool done = false;
-    for (uint64_t mul = 2; mul <= 64 && !done; mul *= 2) {
-      const uint64_t cap = std::max<uint64_t>(mul * n_work, 256);
-      std::vector<double> dd(cap * (uint64_t)(7 + 7 + 1 + 2 + 13 + 13 + 3 * lv));
-      std::vector<int32_t> ii(cap * (uint64_t)(5 + 2 * lv) + RTC_WF_COUNTS);
+    for (uint64_t eighths = 9; eighths <= 512 && !done; eighths *= 2) {
+      const uint64_t cap = std::max<uint64_t>((n_work * eighths + 7) / 8, 256);
+      std::vector<unsigned char> mem(dwave_bytes(cap, lv), 0xCD);  // hipMalloc does not zero either: nothing may rely on it
       DWave W{};
-      double* d = dd.data();
-      W.rq[0] = d; d += 7 * cap; W.rq[1] = d; d += 7 * cap; W.h_t = d; d += cap; W.h_n12 = d; d += 2 * cap; W.sr[0] = d; d += 13 * cap; W.sr[1] = d; d += 13 * cap; W.contrib = d;
-      int32_t* q = ii.data();
-      W.h_prim = q; q += cap; W.sr_mat[0] = q; q += cap; W.sr_mat[1] = q; q += cap; W.sr_node[0] = q; q += cap; W.sr_node[1] = q; q += cap; W.child = q; q += 2 * (uint64_t)lv * cap;
-      W.counts = (uint32_t*)q;
-      W.cap = (uint32_t)cap;
+      dwave_carve(&W, mem.data(), cap, lv);
+      std::memset(W.counts, 0, RTC_WF_COUNTS * sizeof(uint32_t));
       std::memset(&st, 0, sizeof(st));
-      rtc_launch_wavefront(s->d, cam, pm, fuel, W, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr, 5);
+      rtc_launch_wavefront(s->d, cam, pm, fuel, W, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr, 5, 3);
       done = W.counts[RTC_WF_OVERFLOW] == 0;
       if (done) n_launches = 2u * (unsigned)fuel + 4u;
     }
