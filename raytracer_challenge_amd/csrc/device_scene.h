@@ -148,6 +148,7 @@ struct DScene {
   int32_t has_mesh;          // 1: the program contains an OP_MESH
   int32_t has_csg;           // 1: the program contains an OP_CSG
   int32_t has_groups;        // 0: no gates; 1: only OP_MESH / OP_CSG ops are gated; 2: individual primitives are gated
+  int32_t has_recs;          // 1: some op reads intersection records (pisect): analytic BVH, quirk scans, primitives outside the kernel arguments
   // Kernel-argument copy of a short traversal program (kernargs are read with scalar loads: the op fetch and the plane
   // records stop being per-lane vector loads on every ray's dependency chain).  Used when n_kops > 0: the whole program
   // has <= RTC_KOPS ops, no OP_GROUP / OP_CSG, no per-primitive gates (so every lane runs the same op sequence); an

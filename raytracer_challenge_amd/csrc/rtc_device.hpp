@@ -327,6 +327,62 @@ __device__ __forceinline__ int prim_hits(const DScene& S, const DPrimI& P, const
   return n;
 }
 
+// Block-local copy of the scene's hot tables (kernels instantiated with LDSC = true: scenes whose accelerator and intersection
+// records fit a CU's 160 KB of LDS beside the traversal stacks; the block copies them in once and every dependent node / record
+// fetch of a walk is then an LDS read of ~100 cycles instead of an L1 / L2 round trip).  Tables are stored row by row (row r of
+// element n at [r * count + n], 16 B each) so that lanes reading the same row of different elements spread over the banks.
+struct LdsScene {
+  const float4* nodes;   // 7 rows: lox loy loz hix hiy hiz child refs
+  const float4* recs;    // 8 rows: {geom, flags, data, gcond} {mn, mx} m[0..11]   (scenes whose program reads records)
+  const double* tris;    // 9 rows: p1 e1 e2 xyz of the leaf-order triangles        (scenes with a mesh BVH)
+  const int32_t* tri_prim;
+  int n_nodes, n_recs, n_tris;
+};
+__device__ __forceinline__ int4 as_int4(const float4 v) { int4 r; __builtin_memcpy(&r, &v, 16); return r; }
+__device__ __forceinline__ DPrimI lds_record(const LdsScene& L, int prim) {
+  DPrimI P;
+  float4 rows[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) rows[r] = L.recs[r * L.n_recs + prim];
+  __builtin_memcpy(&P, rows, sizeof(P));
+  return P;
+}
+// bytes of the tables (host + device agree on the layout: nodes, records, triangles, triangle -> primitive, 16-byte aligned pieces)
+static inline unsigned long long rtc_lds_table_bytes(const DScene& S) {
+  unsigned long long b = 7ull * 16 * (unsigned)S.n_bvh;
+  if (S.has_recs) b += 8ull * 16 * (unsigned)S.n_prims;
+  if (S.has_mesh) b += (72ull * (unsigned)S.n_mtri + 4ull * (unsigned)S.n_mtri + 15ull) & ~15ull;
+  return b;
+}
+#ifndef RTC_EMU
+// The block copies the tables from memory into dynamic LDS at `base`; returns the first byte after them (the traversal stacks).
+__device__ __forceinline__ char* lds_fill(const DScene& S, char* base, LdsScene& L) {
+  float4* ln = (float4*)base;
+  const float4* gn = (const float4*)S.bvh;
+  for (int k = (int)threadIdx.x; k < 8 * S.n_bvh; k += (int)blockDim.x) { const int n = k >> 3, r = k & 7; if (r < 7) ln[r * S.n_bvh + n] = gn[k]; }
+  char* p = (char*)(ln + 7 * (size_t)S.n_bvh);
+  L.nodes = ln; L.n_nodes = S.n_bvh;
+  L.recs = nullptr; L.n_recs = 0; L.tris = nullptr; L.tri_prim = nullptr; L.n_tris = 0;
+  if (S.has_recs) {
+    float4* lr = (float4*)p;
+    const float4* gr = (const float4*)S.pisect;
+    for (int k = (int)threadIdx.x; k < 8 * S.n_prims; k += (int)blockDim.x) { const int n = k >> 3, r = k & 7; lr[r * S.n_prims + n] = gr[k]; }
+    L.recs = lr; L.n_recs = S.n_prims;
+    p = (char*)(lr + 8 * (size_t)S.n_prims);
+  }
+  if (S.has_mesh) {
+    double* lt = (double*)p;
+    for (int k = (int)threadIdx.x; k < 9 * S.n_mtri; k += (int)blockDim.x) { const int n = k / 9, c = k - 9 * n; lt[c * S.n_mtri + n] = S.mtri[k]; }
+    int32_t* lp = (int32_t*)(lt + 9 * (size_t)S.n_mtri);
+    for (int k = (int)threadIdx.x; k < S.n_mtri; k += (int)blockDim.x) lp[k] = S.mtri_prim[k];
+    L.tris = lt; L.tri_prim = lp; L.n_tris = S.n_mtri;
+    p += (72ull * (unsigned)S.n_mtri + 4ull * (unsigned)S.n_mtri + 15ull) & ~15ull;
+  }
+  __syncthreads();
+  return p;
+}
+#endif
+
 // Shape::intersect (src/shape.rs:414-417) for one primitive.
 // Two reference quirks let a primitive report an intersection OUTSIDE any finite bound of its surface, so a
 // bounding-volume hierarchy alone would lose them:
@@ -337,9 +393,9 @@ __device__ __forceinline__ int prim_hits(const DScene& S, const DPrimI& P, const
 // FEAT: feature level of the kernel instantiation — 0: no groups, no CSG in the scene (no gate code at all); 1: only whole
 // meshes are gated (one uncached chain walk per OP_MESH: the teapot scenes); 2: per-primitive gates with the per-ray cache;
 // 3: + CSG.  Keeps the common kernels under the register cliff.
-template <int FEAT>
-__device__ __forceinline__ void visit_prim(const DScene& S, int prim, const Ray& r, Trav& T, Counters& C, int policy) {
-  const DPrimI P = S.pisect[prim];
+template <int FEAT, bool LDSC = false>
+__device__ __forceinline__ void visit_prim(const DScene& S, int prim, const Ray& r, Trav& T, Counters& C, int policy, const LdsScene& L = LdsScene{}) {
+  const DPrimI P = LDSC ? lds_record(L, prim) : S.pisect[prim];
   if (FEAT >= 2 && P.gcond >= 0 && !groups_pass(S, P.gcond, r, T, C)) return;
   const double* __restrict__ m = P.m;
   if (policy == 0) { DIAG_LOOP(9); } else if (policy == 1) { DIAG_LOOP(10); } else { DIAG_LOOP(11); }
@@ -379,13 +435,13 @@ __device__ __forceinline__ void visit_prim(const DScene& S, int prim, const Ray&
 }
 
 // Direction-grid culled quirk scan (device_scene.h OP_QGRID).  The cell lookup must mirror build_quirk_grid().
-template <int FEAT>
-__device__ __forceinline__ void quirk_grid_scan(const DScene& S, const DQuirkGrid G, const Ray& r, Trav& T, Counters& C) {
+template <int FEAT, bool LDSC = false>
+__device__ __forceinline__ void quirk_grid_scan(const DScene& S, const DQuirkGrid G, const Ray& r, Trav& T, Counters& C, const LdsScene& L = LdsScene{}) {
   DIAG_LOOP(21);
   double ax = fabs(r.dx), ay = fabs(r.dy), az = fabs(r.dz);
   double len2 = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
   if (!(len2 >= RTC_QGRID_MIN_LEN * RTC_QGRID_MIN_LEN) || !(len2 < DINF)) {
-    for (int i = G.lin_first; i < G.lin_first + G.lin_count; i++) visit_prim<FEAT>(S, S.quirk_prim[i], r, T, C, 2);
+    for (int i = G.lin_first; i < G.lin_first + G.lin_count; i++) visit_prim<FEAT, LDSC>(S, S.quirk_prim[i], r, T, C, 2, L);
     return;
   }
   int face;
@@ -398,7 +454,7 @@ __device__ __forceinline__ void quirk_grid_scan(const DScene& S, const DQuirkGri
   iv = iv < 0 ? 0 : (iv >= G.n ? G.n - 1 : iv);
   int cell = G.cell_off + (face * G.n + iv) * G.n + iu;
   unsigned b = S.qcell[cell], e = S.qcell[cell + 1];
-  for (unsigned i = b; i < e; i++) visit_prim<FEAT>(S, S.qitem[i], r, T, C, 2);
+  for (unsigned i = b; i < e; i++) visit_prim<FEAT, LDSC>(S, S.qitem[i], r, T, C, 2, L);
 }
 
 // ---- accelerator -------------------------------------------------------------------------------------
@@ -517,9 +573,9 @@ __device__ __forceinline__ void walk_root_k(const DBvhNode4& R, const Frame32& F
 // The walk itself, from (cur, sp): ONE inlined copy per traversal (the op loop sets the walk up per lane and all walks of a
 // program — mesh or analytic, kernel-argument root or not — run through this loop).  `mesh` is uniform across the wave (it comes
 // from the program op): leaves hold triangles of the packed arrays (object-space ray `o`) or name one analytic primitive.
-template <int FEAT>
+template <int FEAT, bool LDSC = false>
 __device__ __forceinline__ void walk_loop(const DScene& S, const bool mesh, int cur, int sp, const Frame32& F, const Ray& world, const Ray& o, Trav& T, Counters& C,
-                                          int* __restrict__ stack, int stride) {
+                                          int* __restrict__ stack, int stride, const LdsScene& L = LdsScene{}) {
   const int END = RTC_WALK_END;
   const bool any_hit = T.mode == MODE_SHADOW_ANY && T.unordered;  // wavefront shadow role only: 3 % there, -2 % in the one-kernel path
   float lo, hi;  // the pass's t interval in f32 (widened): only a leaf test can change it
@@ -530,11 +586,20 @@ __device__ __forceinline__ void walk_loop(const DScene& S, const bool mesh, int 
     // already hold a leaf wait here, so the expensive leaf tests below run with as many lanes as possible.
     while (cur >= 0) {
       DIAG_LOOP(3);
-      const DBvhNode4* N = S.bvh + cur;
       C.accel_nodes++;
-      // the node's seven 16-byte rows: one line, all loads in flight together
-      const float4 lox = ld4(N->lox), loy = ld4(N->loy), loz = ld4(N->loz), hix = ld4(N->hix), hiy = ld4(N->hiy), hiz = ld4(N->hiz);
-      const int4 cc = ld4(N->c);
+      float4 lox, loy, loz, hix, hiy, hiz;
+      int4 cc;
+      if (LDSC) {
+        const float4* N = L.nodes + cur;
+        const int n = L.n_nodes;
+        lox = N[0]; loy = N[n]; loz = N[2 * n]; hix = N[3 * n]; hiy = N[4 * n]; hiz = N[5 * n];
+        cc = as_int4(N[6 * n]);
+      } else {
+        // the node's seven 16-byte rows: one line, all loads in flight together
+        const DBvhNode4* N = S.bvh + cur;
+        lox = ld4(N->lox); loy = ld4(N->loy); loz = ld4(N->loz); hix = ld4(N->hix); hiy = ld4(N->hiy); hiz = ld4(N->hiz);
+        cc = ld4(N->c);
+      }
       node_step(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride, any_hit);
     }
     if (cur == END) return;
@@ -546,11 +611,16 @@ __device__ __forceinline__ void walk_loop(const DScene& S, const bool mesh, int 
           DIAG_LOOP(1);
           double t, u, v;
           C.tri_tests++;
-          if (tri_hit(S.mtri + 9 * (size_t)i, o, t, u, v)) accept(T, C, S.mtri_prim[i], 1, &t);
+          if (LDSC) {
+            double g[9];
+#pragma unroll
+            for (int c = 0; c < 9; c++) g[c] = L.tris[c * L.n_tris + i];
+            if (tri_hit(g, o, t, u, v)) accept(T, C, L.tri_prim[i], 1, &t);
+          } else if (tri_hit(S.mtri + 9 * (size_t)i, o, t, u, v)) accept(T, C, S.mtri_prim[i], 1, &t);
         }
       } else {
         DIAG_LOOP(1);
-        visit_prim<FEAT>(S, first, world, T, C, 1);  // analytic leaf = one primitive, named by the ref itself
+        visit_prim<FEAT, LDSC>(S, first, world, T, C, 1, L);  // analytic leaf = one primitive, named by the ref itself
       }
       DIAG_SPAN_END(6);
       if (T.mode == MODE_SHADOW_ANY && T.shadowed) return;
@@ -640,8 +710,8 @@ __device__ __noinline__ int csg_eval(const DScene& S, int pc, const Ray& r, Trav
 // records are scalar loads); else the program array in memory (any length, OP_GROUP jumps, per-primitive gates, CSG).  A kernel
 // instantiation has exactly one of the two, and each has exactly ONE inlined copy of the BVH walk.
 // MODE (optional): the pass kind as a compile-time constant (the caller set T.mode to it); -1 = read T.mode at run time.
-template <int FEAT, bool KOPS, int MODE = -1>
-__device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T, Counters& C, int* __restrict__ stack, int stride) {
+template <int FEAT, bool KOPS, int MODE = -1, bool LDSC = false>
+__device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T, Counters& C, int* __restrict__ stack, int stride, const LdsScene& L = LdsScene{}) {
   if (MODE >= 0) T.mode = MODE;
   if (KOPS) {
     for (int pc = 0; pc < S.n_kops; pc++) {
@@ -666,13 +736,13 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
             accept(T, C, P.prim, 1, &t);
           }
         } else {
-          visit_prim<FEAT>(S, op.a, r, T, C, 0);
+          visit_prim<FEAT, LDSC>(S, op.a, r, T, C, 0, L);
         }
       } else if (op.op == OP_QUIRK) {
-        for (int i = op.a; i < op.a + op.b; i++) visit_prim<FEAT>(S, S.quirk_prim[i], r, T, C, 2);
+        for (int i = op.a; i < op.a + op.b; i++) visit_prim<FEAT, LDSC>(S, S.quirk_prim[i], r, T, C, 2, L);
       } else if (op.op == OP_QGRID) {
         DIAG_SPAN_BEGIN();
-        quirk_grid_scan<FEAT>(S, op.pad[0] >= 0 ? S.kqgrid : S.qgrids[op.a], r, T, C);
+        quirk_grid_scan<FEAT, LDSC>(S, op.pad[0] >= 0 ? S.kqgrid : S.qgrids[op.a], r, T, C, L);
         DIAG_SPAN_END(4);
       } else if (!mesh || FEAT == 0 || op.g < 0 || groups_pass<false>(S, op.g, r, T, C)) {  // OP_MESH / OP_BVH
         walk = true;
@@ -690,7 +760,7 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
           make_frame(S.bvh_frame + 4 * op.c, o, F);
         }
       }
-      if (walk) walk_loop<FEAT>(S, mesh, cur, sp, F, r, o, T, C, stack, stride);
+      if (walk) walk_loop<FEAT, LDSC>(S, mesh, cur, sp, F, r, o, T, C, stack, stride, L);
       if (T.mode == MODE_SHADOW_ANY && T.shadowed) return;
     }
     return;
@@ -704,14 +774,14 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
     Frame32 F;
     Ray o = r;
     if (op.op == OP_PRIM) {
-      visit_prim<FEAT>(S, op.a, r, T, C, 0);
+      visit_prim<FEAT, LDSC>(S, op.a, r, T, C, 0, L);
       pc++;
     } else if (op.op == OP_QUIRK) {
-      for (int i = op.a; i < op.a + op.b; i++) visit_prim<FEAT>(S, S.quirk_prim[i], r, T, C, 2);
+      for (int i = op.a; i < op.a + op.b; i++) visit_prim<FEAT, LDSC>(S, S.quirk_prim[i], r, T, C, 2, L);
       pc++;
     } else if (op.op == OP_QGRID) {
       DIAG_SPAN_BEGIN();
-      quirk_grid_scan<FEAT>(S, S.qgrids[op.a], r, T, C);
+      quirk_grid_scan<FEAT, LDSC>(S, S.qgrids[op.a], r, T, C, L);
       DIAG_SPAN_END(4);
       pc++;
     } else if (op.op == OP_GROUP) {
@@ -729,7 +799,7 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
       }
       pc++;
     }
-    if (walk) walk_loop<FEAT>(S, mesh, op.a, 0, F, r, o, T, C, stack, stride);
+    if (walk) walk_loop<FEAT, LDSC>(S, mesh, op.a, 0, F, r, o, T, C, stack, stride, L);
     if (T.mode == MODE_SHADOW_ANY && T.shadowed) return;
   }
 }
@@ -1107,8 +1177,13 @@ __device__ __forceinline__ Ray slot_ray(const DPixelMap& pm, const DCamera& cam,
 // One-kernel path: one lane walks one pixel's whole ray tree (closest pass, shading, shadow passes, pending children); the wave
 // ends with its slowest pixel.  (A persistent variant whose lanes took the next work id from a global counter was measured at
 // -4 % / +14 % and removed in round 2.)
-template <bool COUNT, int FEAT, bool KOPS>
-__global__ void __launch_bounds__(RTC_BLOCK, (FEAT >= 2 && RTC_WAVES_PER_SIMD < 2) ? 2 : RTC_WAVES_PER_SIMD) rtc_trace_kernel(DScene S, DCamera cam, DPixelMap pm, int fuel0, double* __restrict__ rgb, double* __restrict__ hit_t,
+// WAVES: waves per SIMD the kernel is compiled for; 0 = the default budget (every instantiation then lands at 2: 205-256 VGPRs).
+// Scenes whose accelerator does not fit the L2s (config 5: 400 MB) are bound by node-fetch latency and run 13 % faster at 3 waves
+// (168 VGPRs, more spills); cache-resident scenes are 3-9 % slower there (profiles/r2_onekernel_occupancy.txt).
+// (LDS-resident scene tables, as in wf_ts, were measured on this kernel too — 256-thread blocks, two per CU — and lost 10 % on
+// config 3: its 22 KB of nodes and triangles already hit in L1, and a block retires with its slowest wave.)
+template <bool COUNT, int FEAT, bool KOPS, int WAVES = 0>
+__global__ void __launch_bounds__(RTC_BLOCK, WAVES ? WAVES : ((FEAT >= 2 && RTC_WAVES_PER_SIMD < 2) ? 2 : RTC_WAVES_PER_SIMD)) rtc_trace_kernel(DScene S, DCamera cam, DPixelMap pm, int fuel0, double* __restrict__ rgb, double* __restrict__ hit_t,
                                                         int* __restrict__ hit_prim, int* __restrict__ hit_k, DStats* __restrict__ stats) {
   RTC_LDS_STACK(lds_stack);
   int* stack = lds_stack + threadIdx.x;
@@ -1341,10 +1416,10 @@ __device__ __forceinline__ Ray wf_load_ray(const DWave& W, int level, unsigned i
 }  // namespace
 
 // wf_ts work item of the trace role: ray i of `level` (closest hit, container pass for transparent hits).
-template <int FEAT, bool KOPS>
+template <int FEAT, bool KOPS, bool LDSC>
 __device__ __forceinline__ void wf_trace_ray(const DScene& S, const DCamera& cam, const DPixelMap& pm, const DWave& W, const WorkMap& wm, int level, unsigned i,
                                              double* __restrict__ hit_t, int* __restrict__ hit_prim, int* __restrict__ hit_k, int* stack, int stride, Counters& C,
-                                             unsigned& n_rays, unsigned& n_container, int fuel_left) {
+                                             unsigned& n_rays, unsigned& n_container, int fuel_left, const LdsScene& L) {
   const size_t cap = W.cap;
   int32_t* ch = W.child + (size_t)level * 2 * cap;
   Ray ray;
@@ -1359,7 +1434,7 @@ __device__ __forceinline__ void wf_trace_ray(const DScene& S, const DCamera& cam
   n_rays++;
   Trav T;
   reset_closest(T, MODE_CLOSEST);
-  traverse<FEAT, KOPS, MODE_CLOSEST>(S, ray, T, C, stack, stride);
+  traverse<FEAT, KOPS, MODE_CLOSEST, LDSC>(S, ray, T, C, stack, stride, L);
   const bool did_hit = T.best_prim != 0x7fffffff;
   if (level == 0 && hit_t) {
     hit_t[q] = did_hit ? T.best_t : 0.0;
@@ -1380,7 +1455,7 @@ __device__ __forceinline__ void wf_trace_ray(const DScene& S, const DCamera& cam
     K.mode = MODE_CONTAINERS;
     K.tlo = -DINF; K.thi = T.best_t;
     K.c1_prim = -1; K.c2_prim = -1; K.c1_t = 0.0; K.c2_t = 0.0;
-    traverse<FEAT, KOPS, MODE_CONTAINERS>(S, ray, K, C, stack, stride);
+    traverse<FEAT, KOPS, MODE_CONTAINERS, LDSC>(S, ray, K, C, stack, stride, L);
     if (K.c1_prim >= 0) n1 = S.mat[8 * S.prims[K.c1_prim].mat + 6];
     if (K.c2_prim >= 0) n2 = S.mat[8 * S.prims[K.c2_prim].mat + 6];
     W.h_n12[i] = n1; W.h_n12[cap + i] = n2;
@@ -1388,9 +1463,9 @@ __device__ __forceinline__ void wf_trace_ray(const DScene& S, const DCamera& cam
 }
 
 // wf_ts work item of the shadow role: shade record s of `level` (per light: shadow ray, then the Phong terms).
-template <int FEAT, bool KOPS>
+template <int FEAT, bool KOPS, bool LDSC>
 __device__ __forceinline__ void wf_shadow_rec(const DScene& S, const DCamera& cam, const DPixelMap& pm, const DWave& W, const WorkMap& wm, int level, unsigned s, int* stack,
-                                              int stride, Counters& C, unsigned& n_shadow) {
+                                              int stride, Counters& C, unsigned& n_shadow, const LdsScene& L) {
   const size_t cap = W.cap;
   double* cb = W.contrib + (size_t)level * 3 * cap;
   const double* r = W.sr;
@@ -1409,8 +1484,8 @@ __device__ __forceinline__ void wf_shadow_rec(const DScene& S, const DCamera& ca
     Trav Sh;
     reset_closest(Sh, S.all_cast_shadow ? MODE_SHADOW_ANY : MODE_SHADOW_CLOSEST);
     if (S.all_cast_shadow) { Sh.thi = distance; Sh.unordered = 1; }
-    if (S.all_cast_shadow) traverse<FEAT, KOPS, MODE_SHADOW_ANY>(S, sray, Sh, C, stack, stride);  // mode: a compile-time constant in each
-    else traverse<FEAT, KOPS, MODE_SHADOW_CLOSEST>(S, sray, Sh, C, stack, stride);
+    if (S.all_cast_shadow) traverse<FEAT, KOPS, MODE_SHADOW_ANY, LDSC>(S, sray, Sh, C, stack, stride, L);  // mode: a compile-time constant in each
+    else traverse<FEAT, KOPS, MODE_SHADOW_CLOSEST, LDSC>(S, sray, Sh, C, stack, stride, L);
     bool shadowed;
     if (S.all_cast_shadow) shadowed = Sh.shadowed != 0;
     else shadowed = (Sh.best_prim != 0x7fffffff) && (S.prims[Sh.best_prim].flags & 1u) && (Sh.best_t < distance);
@@ -1470,12 +1545,23 @@ __device__ __forceinline__ void wf_shadow_rec(const DScene& S, const DCamera& ca
 #define RTC_WF_TS_WAVES 3  // waves per SIMD the traversal kernel is compiled for: 168 VGPRs, no scratch.  At 4 (128 VGPRs) the ray and the
                            // leaf record spill around every leaf test: same frame time, +1.7 GB of HBM traffic per frame (profiles/r2_*)
 #endif
-template <bool COUNT, int FEAT, bool KOPS>
-__global__ void __launch_bounds__(RTC_BLOCK, FEAT <= 1 ? RTC_WF_TS_WAVES : 2) wf_ts(DScene S, DCamera cam, DPixelMap pm, DWave W, int tl, int sl, unsigned n0, int slot, int fuel_left,
+#ifndef RTC_LDS_BLOCK
+#define RTC_LDS_BLOCK (256 * RTC_WF_TS_WAVES)  // LDSC kernels: one block per CU with all the waves the register budget allows
+#endif
+template <bool COUNT, int FEAT, bool KOPS, bool LDSC = false>
+__global__ void __launch_bounds__(LDSC ? RTC_LDS_BLOCK : RTC_BLOCK, FEAT <= 1 ? RTC_WF_TS_WAVES : 2) wf_ts(DScene S, DCamera cam, DPixelMap pm, DWave W, int tl, int sl, unsigned n0, int slot, int fuel_left,
                                                                      double* __restrict__ hit_t, int* __restrict__ hit_prim, int* __restrict__ hit_k, DStats* __restrict__ stats) {
   RTC_LDS_STACK(lds_stack);
+  LdsScene L = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
   int* stack = lds_stack + threadIdx.x;
-  const int stride = RTC_BLOCK;
+  int stride = RTC_BLOCK;
+#ifndef RTC_EMU
+  if (LDSC) {
+    // dynamic LDS: [scene tables][blockDim x bvh_stack stack words]; the block copies the tables in
+    stack = (int*)lds_fill(S, (char*)lds_stack, L) + threadIdx.x;
+    stride = (int)blockDim.x;
+  }
+#endif
   Counters C = {0, 0, 0, 0, 0, 0, 0};
   unsigned n_rays = 0, n_container = 0, n_shadow = 0;
   const WorkMap wm = make_workmap(pm, cam);
@@ -1497,13 +1583,13 @@ __global__ void __launch_bounds__(RTC_BLOCK, FEAT <= 1 ? RTC_WF_TS_WAVES : 2) wf
       const unsigned base = (unsigned)chunk * RTC_WF_CHUNK;
       for (unsigned o = 0; o < RTC_WF_CHUNK; o += RTC_WF_LANES) {
         const unsigned i = base + o + (unsigned)lane;
-        if (i < nt) wf_trace_ray<FEAT, KOPS>(S, cam, pm, W, wm, tl, i, hit_t, hit_prim, hit_k, stack, stride, C, n_rays, n_container, fuel_left);
+        if (i < nt) wf_trace_ray<FEAT, KOPS, LDSC>(S, cam, pm, W, wm, tl, i, hit_t, hit_prim, hit_k, stack, stride, C, n_rays, n_container, fuel_left, L);
       }
     } else {
       const unsigned base = (unsigned)(chunk - ct) * RTC_WF_CHUNK;
       for (unsigned o = 0; o < RTC_WF_CHUNK; o += RTC_WF_LANES) {
         const unsigned s = base + o + (unsigned)lane;
-        if (s < ns) wf_shadow_rec<FEAT, KOPS>(S, cam, pm, W, wm, sl, s, stack, stride, C, n_shadow);
+        if (s < ns) wf_shadow_rec<FEAT, KOPS, LDSC>(S, cam, pm, W, wm, sl, s, stack, stride, C, n_shadow, L);
       }
     }
   }

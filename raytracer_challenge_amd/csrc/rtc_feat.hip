@@ -35,8 +35,16 @@
 #define RTC_V_KOPS false
 #endif
 
-void RTC_CAT(rtc_launch_trace_v, RTC_VARIANT)(bool count, unsigned grid, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb,
+void RTC_CAT(rtc_launch_trace_v, RTC_VARIANT)(bool count, int waves, unsigned grid, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb,
                                               double* hit_t, int* hit_prim, int* hit_k, DStats* stats) {
+#if RTC_VARIANT == 1 || RTC_VARIANT == 2
+  // mesh scenes larger than the L2s: the 3-waves-per-SIMD build (see rtc_trace_kernel)
+  if (waves == 3 && !count) {
+    hipLaunchKernelGGL((rtc_trace_kernel<false, RTC_V_FEAT, RTC_V_KOPS, 3>), dim3(grid), dim3(RTC_BLOCK), rtc_stack_bytes(S), stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats);
+    return;
+  }
+#endif
+  (void)waves;
   if (count) hipLaunchKernelGGL((rtc_trace_kernel<true, RTC_V_FEAT, RTC_V_KOPS>), dim3(grid), dim3(RTC_BLOCK), rtc_stack_bytes(S), stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats);
   else hipLaunchKernelGGL((rtc_trace_kernel<false, RTC_V_FEAT, RTC_V_KOPS>), dim3(grid), dim3(RTC_BLOCK), rtc_stack_bytes(S), stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats);
 }
@@ -48,6 +56,25 @@ void RTC_CAT(rtc_launch_wf_ts_v, RTC_VARIANT)(bool count, unsigned grid, hipStre
 }
 
 #ifndef RTC_EMU
+// The same kernel with the scene's accelerator nodes and intersection records copied into LDS by every block (variants with a
+// kernel-argument program only: those are the small scenes); one block of RTC_LDS_BLOCK threads per CU, `lds_bytes` of dynamic LDS.
+void RTC_CAT(rtc_launch_wf_ts_lds_v, RTC_VARIANT)(bool count, unsigned grid, unsigned lds_bytes, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm,
+                                                  const DWave& W, int tl, int sl, unsigned n0, int slot, int fuel_left, double* hit_t, int* hit_prim, int* hit_k, DStats* stats) {
+#if RTC_VARIANT <= 1
+  static bool raised = false;
+  if (!raised) {  // more than 64 KB of dynamic LDS has to be asked for
+    (void)hipFuncSetAttribute((const void*)wf_ts<true, RTC_V_FEAT, RTC_V_KOPS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)wf_ts<false, RTC_V_FEAT, RTC_V_KOPS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    raised = true;
+  }
+  if (count) hipLaunchKernelGGL((wf_ts<true, RTC_V_FEAT, RTC_V_KOPS, true>), dim3(grid), dim3(RTC_LDS_BLOCK), lds_bytes, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
+  else hipLaunchKernelGGL((wf_ts<false, RTC_V_FEAT, RTC_V_KOPS, true>), dim3(grid), dim3(RTC_LDS_BLOCK), lds_bytes, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
+#else
+  RTC_CAT(rtc_launch_wf_ts_v, RTC_VARIANT)(count, grid, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
+  (void)lds_bytes;
+#endif
+}
+
 // resident waves per CU of this variant's traversal kernel (the persistent grid of the wavefront path)
 int RTC_CAT(rtc_wf_ts_blocks_per_cu_v, RTC_VARIANT)(unsigned lds_bytes) {
   int nb = 0;

@@ -1,14 +1,18 @@
 // rtc_kernels.hip — hand-written HIP for gfx950 (MI355X): the kernels of the hot path that do not depend on the scene's feature
 // level (wf_shade, wf_gather, the quantiser) and the host-callable launchers.  The ray kernels (rtc_trace_kernel, wf_ts) are
 // templates in rtc_device.hpp, instantiated per feature level by rtc_feat.hip (one translation unit per level, built in parallel).
+#include <cstdlib>
+
 #include "rtc_device.hpp"
 
 #define RTC_VARIANT_DECL(N)                                                                                                                                   \
-  void rtc_launch_trace_v##N(bool count, unsigned grid, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, \
+  void rtc_launch_trace_v##N(bool count, int waves, unsigned grid, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, \
                              double* hit_t, int* hit_prim, int* hit_k, DStats* stats);                                                                       \
   void rtc_launch_wf_ts_v##N(bool count, unsigned grid, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, const DWave& W, int tl, \
                              int sl, unsigned n0, int slot, int fuel_left, double* hit_t, int* hit_prim, int* hit_k, DStats* stats);                         \
-  int rtc_wf_ts_blocks_per_cu_v##N(unsigned lds_bytes);
+  int rtc_wf_ts_blocks_per_cu_v##N(unsigned lds_bytes);                                                                                                        \
+  void rtc_launch_wf_ts_lds_v##N(bool count, unsigned grid, unsigned lds_bytes, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm,   \
+                                 const DWave& W, int tl, int sl, unsigned n0, int slot, int fuel_left, double* hit_t, int* hit_prim, int* hit_k, DStats* stats);
 RTC_VARIANT_DECL(0) RTC_VARIANT_DECL(1) RTC_VARIANT_DECL(2) RTC_VARIANT_DECL(3) RTC_VARIANT_DECL(4)
 #undef RTC_VARIANT_DECL
 #ifdef RTC_EMU
@@ -209,6 +213,20 @@ static void launch_wf_ts(int v, bool count, unsigned grid, hipStream_t stream, c
 }
 
 #ifndef RTC_EMU
+// LDS-resident scene (rtc_device.hpp, LdsScene): bytes of dynamic LDS a block of the LDSC traversal kernel needs, or 0 when the
+// scene does not qualify (program not in the kernel arguments, tables + stacks beyond a CU's 160 KB) or RTC_WF_LDS=0.
+unsigned rtc_wavefront_lds_bytes(const DScene& S) {
+  static const bool off = [] { const char* e = std::getenv("RTC_WF_LDS"); return e && e[0] == '0'; }();
+  if (off || rtc_variant(S) > 1) return 0;
+  const unsigned long long need = rtc_lds_table_bytes(S) + (unsigned long long)RTC_LDS_BLOCK * (unsigned)S.bvh_stack * sizeof(int);
+  return need <= 158ull * 1024 ? (unsigned)need : 0u;
+}
+static void launch_wf_ts_lds(int v, bool count, unsigned grid, unsigned lds, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, const DWave& W, int tl,
+                             int sl, unsigned n0, int slot, int fuel_left, double* hit_t, int* hit_prim, int* hit_k, DStats* stats) {
+  if (v == 0) rtc_launch_wf_ts_lds_v0(count, grid, lds, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
+  else rtc_launch_wf_ts_lds_v1(count, grid, lds, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
+}
+
 // Grid of the wavefront traversal kernel: as many one-wave blocks as the chip holds at once (the kernel hands out chunks
 // itself), from the occupancy the runtime reports for this scene's variant and LDS stack size.
 unsigned rtc_wavefront_grid(const DScene& S, int n_cu) {
@@ -239,10 +257,18 @@ void rtc_launch_wavefront(const DScene& S, const DCamera& cam, const DPixelMap& 
   if (pm.n == 0) return;
   const int v = rtc_variant(S);
   const unsigned n0 = (unsigned)rtc_wavefront_work(cam, pm);
+#ifndef RTC_EMU
+  const unsigned lds = rtc_wavefront_lds_bytes(S);
+  const unsigned lds_blocks = std::max(1u, shade_blocks / 2u);  // one block per CU (the shading grid is two per CU)
+#endif
   const dim3 sgrid(std::max(1u, shade_blocks)), sblock(RTC_WF_SHADE_BLOCK);
   // trace_0; shade_0; [shadow_0 + trace_1]; shade_1; ... [shadow_{fuel-1} + trace_fuel]; shade_fuel; shadow_fuel; sums
   for (int level = 0; level <= fuel + 1; level++) {
     const int tl = level <= fuel ? level : -1, sl = level - 1;
+#ifndef RTC_EMU
+    if (lds) launch_wf_ts_lds(v, count, lds_blocks, lds, stream, S, cam, pm, W, tl, sl, n0, level, fuel - level, hit_t, hit_prim, hit_k, stats);
+    else
+#endif
     launch_wf_ts(v, count, blocks, stream, S, cam, pm, W, tl, sl, n0, level, fuel - level, hit_t, hit_prim, hit_k, stats);
     if (level <= fuel) {
       if (count) hipLaunchKernelGGL((wf_shade<true>), sgrid, sblock, 0, stream, S, cam, pm, W, level, n0, fuel, stats);
@@ -290,16 +316,17 @@ void rtc_launch_deinterleave(const double* slab, double* image, unsigned rowlen,
   hipLaunchKernelGGL(rtc_deinterleave_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slab, image, rowlen, vsize, n, max_rows);
 }
 
-// One-kernel path: one lane per work id (tile padding included).
+// One-kernel path: one lane per work id (tile padding included).  big_scene: the accelerator does not fit the L2s.
 void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
-                      DStats* stats, bool count, hipStream_t stream) {
+                      DStats* stats, bool count, hipStream_t stream, bool big_scene) {
   if (pm.n == 0) return;
   const unsigned grid = (unsigned)((rtc_wavefront_work(cam, pm) + RTC_BLOCK - 1) / RTC_BLOCK);
+  const int waves = big_scene ? 3 : 0;
   switch (rtc_variant(S)) {
-    case 0: rtc_launch_trace_v0(count, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats); break;
-    case 1: rtc_launch_trace_v1(count, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats); break;
-    case 2: rtc_launch_trace_v2(count, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats); break;
-    case 3: rtc_launch_trace_v3(count, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats); break;
-    default: rtc_launch_trace_v4(count, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats); break;
+    case 0: rtc_launch_trace_v0(count, waves, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats); break;
+    case 1: rtc_launch_trace_v1(count, waves, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats); break;
+    case 2: rtc_launch_trace_v2(count, waves, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats); break;
+    case 3: rtc_launch_trace_v3(count, waves, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats); break;
+    default: rtc_launch_trace_v4(count, waves, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats); break;
   }
 }

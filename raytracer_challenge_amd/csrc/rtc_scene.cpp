@@ -17,7 +17,7 @@
 #include "scene_build.hpp"
 
 void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
-                      DStats* stats, bool count, hipStream_t stream);
+                      DStats* stats, bool count, hipStream_t stream, bool big_scene);
 void rtc_launch_quantize(const double* rgb, unsigned char* out, unsigned long long n, hipStream_t stream);
 void rtc_launch_deinterleave(const double* slab, double* image, unsigned rowlen, unsigned vsize, unsigned n, unsigned max_rows, hipStream_t stream);
 void rtc_launch_wavefront(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, const DWave& W, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
@@ -204,7 +204,7 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
     HIP_OK(hipEventRecord(s->ev0, s->stream));
     rtc_launch_wavefront(s->d, cam, pm, fuel, s->wave, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream, s->wave_blocks, s->shade_blocks);
   } else {
-    rtc_launch_trace(s->d, cam, pm, fuel, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream);
+    rtc_launch_trace(s->d, cam, pm, fuel, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream, s->bytes > (32ull << 20));
   }
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(s->ev1, s->stream));
@@ -321,6 +321,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     d.has_mesh = hv.has_mesh;
     d.has_csg = hv.has_csg;
     d.has_groups = hv.has_groups;
+    d.has_recs = hv.has_recs;
     d.n_kops = hv.n_kops; d.n_kplanes = hv.n_kplanes;
     std::memcpy(d.kops, hv.kops, sizeof(d.kops));
     std::memcpy(d.kplanes, hv.kplanes, sizeof(d.kplanes));

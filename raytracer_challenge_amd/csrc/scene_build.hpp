@@ -511,6 +511,12 @@ struct HostArrays {
     for (int32_t pi : bvh_prims) if (prims[pi].gcond >= 0) d.has_groups = 2;
     for (const DOp& o : ops) { if (o.op == OP_MESH) d.has_mesh = 1; if (o.op == OP_CSG) d.has_csg = 1; }
     fill_kernarg_program(d);
+    d.has_recs = 0;
+    for (size_t i = 0; i < ops.size(); i++) {
+      const DOp& o = ops[i];
+      if (o.op == OP_BVH || o.op == OP_QUIRK || o.op == OP_QGRID || o.op == OP_CSG) d.has_recs = 1;
+      if (o.op == OP_PRIM && (d.n_kops == 0 || d.kops[i].c < 0)) d.has_recs = 1;  // not a plane record of the kernel arguments
+    }
     return d;
   }
 };

@@ -51,10 +51,10 @@ static int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double*
     }
     if (!done) {  // as the product does beyond its memory budget: render again with the one-kernel path
       std::memset(&st, 0, sizeof(st));
-      rtc_launch_trace(s->d, cam, pm, fuel, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr);
+      rtc_launch_trace(s->d, cam, pm, fuel, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr, false);
     }
   } else {
-    rtc_launch_trace(s->d, cam, pm, fuel, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr);
+    rtc_launch_trace(s->d, cam, pm, fuel, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr, false);
   }
   if (hits) for (uint64_t i = 0; i < pm.n; i++) hits[i] = {t[i], p[i], k[i]};
   if (stats) {

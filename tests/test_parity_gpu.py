@@ -45,31 +45,50 @@ def test_hip_edge_rays(hip, orc):
         assert_ray_parity(hip, orc, world, cases.edge_rays(4096), 5, label=name)
 
 
+@pytest.mark.parametrize("path", ["1", "4"])
 @pytest.mark.parametrize("name", sorted(GOLDEN_SCENES))
-def test_hip_matches_reference_render(hip, orc, name):
-    """Sampled pixels of the reference's own 4096-wide renders, exact after the reference's 8-bit quantiser."""
+def test_hip_matches_reference_render(hip, orc, name, path, monkeypatch):
+    """Sampled pixels of the reference's own 4096-wide renders, exact after the reference's 8-bit quantiser — on BOTH device paths
+    (RTC_KERNEL pins the path for pixel-list launches too: 1 = one kernel per launch, 4 = the wavefront kernels)."""
+    monkeypatch.setenv("RTC_KERNEL", path)
     doc, s = load_samples(name)
     cam, world = GOLDEN_SCENES[name]()
     idx = (s[:, 1] * cam.hsize + s[:, 0]).astype(np.uint64)
     rgb, _ = hip.render(hip.build_world(world), cam, 5, idx)
     q = orc.quantize(rgb).astype(np.int64)   # the quantiser (src/color.rs:42-46) is the checker's, applied to HIP output
     bad = np.flatnonzero(np.abs(q - s[:, 2:5]).max(1) > 0)
-    assert bad.size == 0, "%s: %d/%d sampled pixels differ from the reference PNG" % (name, bad.size, len(s))
+    assert bad.size == 0, "%s (path %s): %d/%d sampled pixels differ from the reference PNG" % (name, path, bad.size, len(s))
 
 
-def test_hip_full_size_properties(hip, orc):
-    """BASELINE config 2/3 at 1920x1080, fuel 5: (i) a strided sample of the full frame equals the oracle bit-for-bit in hits;
-    (ii) rendering by explicit index list == rendering the full range (idempotence / order independence);
-    (iii) every primary hit record is self-consistent (miss <=> black primary contribution is not assumed; t >= 0)."""
-    for label, (cam, world) in {"config2": scenes.synthetic_analytic(), "config3": scenes.chapter15_teapot("teapot_low.obj", 1920, 1080)}.items():
+def hits_equal(a, b):
+    return bool(np.array_equal(a["prim"], b["prim"]) and np.array_equal(a["push_idx"], b["push_idx"]) and np.array_equal(a["t"].view(np.uint64), b["t"].view(np.uint64)))
+
+
+@pytest.mark.parametrize("label", ["config2", "config3"])
+def test_hip_full_size_properties(hip, orc, label, monkeypatch):
+    """BASELINE config 2 / 3 at 1920x1080, fuel 5, on BOTH device paths: (i) >= 100 000 pixels of the full frame against the oracle
+    (hits bit-exact, colours <= 1e-5); (ii) rendering by explicit index list == the same pixels of the full-range render
+    (idempotence / order independence); (iii) the two paths give the same bits; (iv) every primary hit record is self-consistent."""
+    cam, world = scenes.synthetic_analytic() if label == "config2" else scenes.chapter15_teapot("teapot_low.obj", 1920, 1080)
+    idx = np.arange(0, 1920 * 1080, 19, dtype=np.uint64)          # 109 137 pixels
+    assert idx.size >= 100000
+    ref_rgb, ref_hits = orc.render(orc.build_world(world), cam, 5, idx)
+    frames = {}
+    for path in ("1", "4"):
+        monkeypatch.setenv("RTC_KERNEL", path)
         nw = hip.build_world(world)
         rgb, hits = hip.render(nw, cam, 5)
         assert rgb.shape == (1920 * 1080, 3) and np.isfinite(rgb).all()
         assert (hits["t"][hits["prim"] >= 0] >= 0).all() and (hits["prim"] < nw.primitive_count).all()
-        idx = np.arange(0, 1920 * 1080, 997, dtype=np.uint64)
-        rgb2, hits2 = hip.render(nw, cam, 5, idx)
-        assert np.array_equal(rgb2, rgb[idx.astype(np.int64)]) and np.array_equal(hits2, hits[idx.astype(np.int64)])
-        assert_parity(hip, orc, world, cam, 5, idx[::4], label=label + " strided sample")
+        sub = np.arange(0, 1920 * 1080, 997, dtype=np.uint64)
+        rgb2, hits2 = hip.render(nw, cam, 5, sub)
+        assert np.array_equal(rgb2, rgb[sub.astype(np.int64)]) and np.array_equal(hits2, hits[sub.astype(np.int64)])
+        ii = idx.astype(np.int64)
+        assert hits_equal(hits[ii], ref_hits), "%s path %s: primary hits differ from the oracle" % (label, path)
+        err = float(np.abs(rgb[ii] - ref_rgb).max())
+        assert err <= RGB_TOL, "%s path %s: max |dRGB| = %.3e" % (label, path, err)
+        frames[path] = (rgb, hits)
+    assert np.array_equal(frames["1"][0], frames["4"][0]) and np.array_equal(frames["1"][1], frames["4"][1])
 
 
 def test_hip_rows_device_matches_host_path(hip):
@@ -192,14 +211,15 @@ def test_hip_config4_teapot_high_4k_fuel8(hip, orc):
     assert np.isfinite(rgb).all() and (hits["prim"] < nw.primitive_count).all()
     on_teapot = np.flatnonzero(hits["prim"] >= 3)
     assert on_teapot.size > 100000
-    idx = np.concatenate([np.arange(0, 3840 * 2160, 41011), on_teapot[::4001]]).astype(np.uint64)
+    idx = np.concatenate([np.arange(0, 3840 * 2160, 2203), on_teapot[::150]]).astype(np.uint64)   # ~3 800 + ~3 000 pixels
+    assert idx.size >= 5000
     assert_parity(hip, orc, world, cam, 8, idx, label="config4 sample (%d px)" % idx.size)
 
 
 def test_hip_config5_million_triangles_noise(hip, orc, tmp_path):
     """BASELINE configs[4] on one GPU: ~10^6-triangle smooth mesh (one OBJ group) with Fractal/Simplex procedural textures,
-    3840x2160, fuel 8.  Full frame on the HIP path; oracle parity on a small pixel sample at fuel 5 (the oracle tests
-    10^6 triangles per ray that enters the group's box); full-size property: index-list render == full-range render."""
+    3840x2160, fuel 8.  Full frame on the HIP path; oracle parity on a small pixel sample AT FUEL 8 (the oracle tests
+    10^6 triangles per ray that enters the group's box: seconds per pixel); full-size property: index-list render == full-range render."""
     path = str(tmp_path / "heightfield_708.obj")
     ntri = scenes.write_heightfield_obj(path, 708, 708, 12345)
     assert ntri == 999698
@@ -213,7 +233,7 @@ def test_hip_config5_million_triangles_noise(hip, orc, tmp_path):
     idx = np.concatenate([np.arange(1000, 3840 * 2160, 3840 * 2160 // 24), on_mesh[:: on_mesh.size // 24]]).astype(np.uint64)
     rgb2, hits2 = hip.render(nw, cam, 8, idx)
     assert np.array_equal(rgb2, rgb[idx.astype(np.int64)]) and np.array_equal(hits2, hits[idx.astype(np.int64)])
-    assert_parity(hip, orc, world, cam, 5, idx, label="config5 sample (%d px)" % idx.size)
+    assert_parity(hip, orc, world, cam, 8, idx, label="config5 sample at fuel 8 (%d px)" % idx.size)
 
 
 def test_hip_quantiser_and_ppm(hip, orc):
