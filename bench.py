@@ -17,7 +17,7 @@ driver launches it.  Rank 0 prints ONE JSON line:
 
   value / ms_per_step   whole-job unique rays of K frames / wall time of the timed region (barrier + synchronize on both sides)
   roofline              bound "hbm": algorithmic bytes per frame that go through the memory system (device.algorithmic_bytes:
-                        SURVEY §8d units on the kernels' own counters; kernel-argument-resident records count 0) / the frame's
+                        SURVEY §8d units on the kernels' own counters; kernel-argument- and LDS-resident records count 0) / the frame's
                         device time, measured with HIP events on the scene's stream over sequential launches; `traffic` =
                         HBM bytes per frame from rocprofv3 PMC passes of THIS workload taken inside this run (child processes),
                         corrected as profiles/pmc_calibration.json says; `hbm_traffic_frac` = traffic / device time / peak
@@ -333,7 +333,7 @@ def measure(args, rtm, dist, workload, fuel, steps, warmup, F, rank, world_size,
            "seq_ms": seq_ms, "path": path, "counters": cst, "n_lights": nw.n_lights, "primitives": nw.primitive_count, "info": dr.info(), "F": F}
     if rank != 0:
         return res
-    alg = algorithmic_bytes(cst, path["path"], nw.primitive_count)
+    alg = algorithmic_bytes(cst, path["path"], nw.primitive_count, lds_tables=dr.info().get("wavefront_lds_bytes_per_block", 0) > 0)
     achieved = alg["memory"] / (seq_ms * 1e-3) / 1e9
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "kernel": ("wavefront frame = wf_ts x%d + wf_shade x%d + wf_gather (dominant: wf_ts)" % (fuel + 2, fuel + 1)) if "wavefront" in path["path"] else "rtc_trace_kernel",

@@ -27,8 +27,9 @@ typedef struct rtc_scene rtc_scene;
 enum {
   RTC_OK = 0,
   RTC_ERR_INVALID = 1,     /* malformed description (index out of range, pattern too deep, ...)        */
-  RTC_ERR_UNSUPPORTED = 2, /* valid in the reference, beyond a device limit (a CSG subtree producing more
-                              than 32 intersections or nested deeper than 8)                            */
+  RTC_ERR_UNSUPPORTED = 2, /* valid in the reference, beyond a device limit: CSG groups nested deeper than 8;
+                              a launch whose CSG intersection slab would exceed RTC_CSG_MAX_BYTES (16 GiB: a
+                              subtree with more than 32 possible intersections gets that many rows per thread) */
   RTC_ERR_DEVICE = 3,      /* HIP failure / no device                                                   */
   RTC_ERR_NAN = 4          /* a NaN intersection t was produced; the reference panics when it sorts it
                               (src/intersection.rs:124)                                                 */
@@ -218,6 +219,11 @@ int rtc_scene_sync(rtc_scene*);
 /* Accelerator facts for reports: traversal-program length, BVH node count (4-wide nodes, 128 B each), triangles packed
  * into mesh BVH leaves, deepest BVH (levels of 4-wide nodes).  Any pointer may be NULL. */
 void rtc_scene_accel_info(const rtc_scene*, uint32_t* n_ops, uint32_t* n_bvh_nodes, uint32_t* n_mesh_tris, uint32_t* bvh_depth);
+
+/* Dynamic LDS (bytes per block) the wavefront traversal kernel uses for this scene: > 0 = the scene's accelerator nodes, intersection
+ * records and mesh triangles are copied into every CU's LDS and walks read them there (small scenes: the tables and the traversal
+ * stacks fit 160 KB); 0 = they are read from memory.  bench.py's byte accounting counts LDS-resident records as 0 bytes. */
+uint32_t rtc_scene_wavefront_lds_bytes(const rtc_scene*);
 
 /* Which device path renders whole-row launches of this scene (both give bit-identical pixels and hits):
  *   1  one kernel: a lane walks its pixel's whole ray tree (rtc_trace_kernel);

@@ -83,8 +83,11 @@ struct DKAux {
 struct DCsg {
   int32_t kind, left_first, left_end, pad;
 };
-#define RTC_CSG_MAX_HITS 32   // intersections one top-level CSG subtree can produce (checked at scene creation)
+#define RTC_CSG_MAX_HITS 32   // intersections of one top-level CSG subtree that fit the per-lane buffer; a scene whose subtrees can
+                              // produce more (DScene.csg_max_hits, computed at scene creation) gets a slab in device memory with
+                              // csg_max_hits entries per lane of the launch (the reference's lists are unbounded, src/shape.rs:248-269)
 #define RTC_CSG_MAX_DEPTH 8
+struct DCsgHit { double t; int32_t prim, k; };
 
 struct DPrim {  // 32 bytes
   int32_t geom;
@@ -131,6 +134,7 @@ struct DScene {
   const DQuirkGrid* qgrids;
   const uint32_t* qcell;     // per-cell offsets into qitem
   const DCsg* csg;
+  DCsgHit* csg_slab;         // csg_max_hits > RTC_CSG_MAX_HITS: csg_max_hits entries per thread of the launch (else NULL)
   const double* bvh_frame;   // per BVH (DOp.c of OP_MESH / OP_BVH): centre xyz + inf-norm radius; node boxes are relative to the centre
   const int32_t* qitem;      // primitive indices
   const DPrim* prims;
@@ -148,6 +152,7 @@ struct DScene {
   int32_t has_mesh;          // 1: the program contains an OP_MESH
   int32_t has_csg;           // 1: the program contains an OP_CSG
   int32_t has_groups;        // 0: no gates; 1: only OP_MESH / OP_CSG ops are gated; 2: individual primitives are gated
+  int32_t csg_max_hits;      // most intersections one top-level CSG subtree can produce
   int32_t has_recs;          // 1: some op reads intersection records (pisect): analytic BVH, quirk scans, primitives outside the kernel arguments
   // Kernel-argument copy of a short traversal program (kernargs are read with scalar loads: the op fetch and the plane
   // records stop being per-lane vector loads on every ray's dependency chain).  Used when n_kops > 0: the whole program

@@ -637,9 +637,13 @@ __device__ __forceinline__ void walk_loop(const DScene& S, const bool mesh, int 
 // insertion order; at each OP_CSG_END the node's range of the buffer is stable-sorted by t and filtered in place — post-order,
 // so a nested CSG hands its parent exactly the list the reference's recursion would.  What survives the outermost filter is
 // fed to the current pass with each entry's own (primitive, push index), so tie-breaks and the container pass see the same keys.
-struct CsgHit { double t; int prim, k; };
+typedef DCsgHit CsgHit;
 __device__ __noinline__ int csg_eval(const DScene& S, int pc, const Ray& r, Trav& T, Counters& C) {
-  CsgHit buf[RTC_CSG_MAX_HITS];
+  CsgHit local[RTC_CSG_MAX_HITS];
+  // scenes whose subtrees can produce more intersections than the per-lane buffer holds: this thread's rows of the launch's slab
+  CsgHit* buf = local;
+  int cap = RTC_CSG_MAX_HITS;
+  if (S.csg_slab) { buf = S.csg_slab + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (size_t)S.csg_max_hits; cap = S.csg_max_hits; }
   int n = 0;
   int frame_begin[RTC_CSG_MAX_DEPTH];
   int depth = 0;
@@ -661,7 +665,7 @@ __device__ __noinline__ int csg_eval(const DScene& S, int pc, const Ray& r, Trav
       double t[4], u = 0.0, v = 0.0;
       if (P.geom >= 5) C.tri_tests++; else C.analytic_tests++;
       int m = prim_hits(S, P, o, t, u, v);
-      for (int j = 0; j < m && n < RTC_CSG_MAX_HITS; j++) {
+      for (int j = 0; j < m && n < cap; j++) {
         if (t[j] != t[j]) C.nan_ts++;  // the reference sorts this list: a NaN t panics (src/intersection.rs:124)
         buf[n].t = t[j]; buf[n].prim = op.a; buf[n].k = j; n++;
       }

@@ -24,6 +24,7 @@ void rtc_launch_wavefront(const DScene& S, const DCamera& cam, const DPixelMap& 
                           DStats* stats, bool count, hipStream_t stream, unsigned blocks, unsigned shade_blocks);
 uint64_t rtc_wavefront_work(const DCamera& cam, const DPixelMap& pm);
 unsigned rtc_wavefront_grid(const DScene& S, int n_cu);
+unsigned rtc_wavefront_lds_bytes(const DScene& S);
 
 static thread_local std::string g_rtc_err;
 static int rtc_fail(int code, const std::string& m) {
@@ -59,6 +60,8 @@ struct rtc_scene {
   double tune_ms[2] = {-1.0, -1.0};
   int tune_n[2] = {0, 0};
   int tune_choice = 0;
+  DCsgHit* csg_slab = nullptr;  // CSG subtrees beyond the per-lane buffer: csg_max_hits rows per thread of the largest launch so far
+  uint64_t csg_slab_threads = 0;
   bool wave_alloc_failed = false;  // the device refused the queues once: launches stay on the one-kernel path
   // wavefront path (RTC_KERNEL=4): queues and per-level arrays, grown on demand
   DWave wave{};
@@ -191,6 +194,22 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
   if (tuned) path = pick_path(s, launch_signature(cam, pm, fuel), rtc_wavefront_work(cam, pm), will_sync, pm.mode != 2);
   if (path == 4 && s->wave_alloc_failed && force == 0) path = 1;
   const bool wavefront = path == 4 && pm.n > 0;
+  if (s->d.csg_max_hits > RTC_CSG_MAX_HITS) {
+    // threads of the launch that walk CSG sub-programs: the one-kernel grid covers every work id, the wavefront traversal grid is persistent
+    const uint64_t threads = wavefront ? (uint64_t)s->wave_blocks * 64ull : ((rtc_wavefront_work(cam, pm) + 63) / 64) * 64;
+    if (threads > s->csg_slab_threads) {
+      const uint64_t bytes = threads * (uint64_t)s->d.csg_max_hits * sizeof(DCsgHit);
+      const char* e = std::getenv("RTC_CSG_MAX_BYTES");
+      if (bytes > (e ? std::strtoull(e, nullptr, 10) : (16ull << 30)))
+        return rtc_fail(RTC_ERR_UNSUPPORTED, "the CSG intersection slab of this launch exceeds RTC_CSG_MAX_BYTES: render fewer pixels per call");
+      HIP_OK(hipStreamSynchronize(s->stream));
+      (void)hipFree(s->csg_slab);
+      s->csg_slab = nullptr; s->csg_slab_threads = 0;
+      HIP_OK(hipMalloc((void**)&s->csg_slab, bytes));
+      s->csg_slab_threads = threads;
+    }
+    s->d.csg_slab = s->csg_slab;
+  }
   if (wavefront) {
     int rc = ensure_wave(s, rtc_wavefront_work(cam, pm), fuel);
     if (rc == RTC_ERR_UNSUPPORTED && force == 0) {
@@ -322,6 +341,8 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     d.has_csg = hv.has_csg;
     d.has_groups = hv.has_groups;
     d.has_recs = hv.has_recs;
+    d.csg_max_hits = hv.csg_max_hits;
+    d.csg_slab = nullptr;
     d.n_kops = hv.n_kops; d.n_kplanes = hv.n_kplanes;
     std::memcpy(d.kops, hv.kops, sizeof(d.kops));
     std::memcpy(d.kplanes, hv.kplanes, sizeof(d.kplanes));
@@ -376,6 +397,7 @@ void rtc_scene_destroy(rtc_scene* s) {
   if (s->d_stats) (void)hipFree(s->d_stats);
   (void)hipFree(s->d_rgb); (void)hipFree(s->d_hit_t); (void)hipFree(s->d_hit_prim); (void)hipFree(s->d_hit_k);
   if (s->wave_mem) (void)hipFree(s->wave_mem);
+  (void)hipFree(s->csg_slab);
   if (s->d_idx) (void)hipFree(s->d_idx);
   if (s->d_rays) (void)hipFree(s->d_rays);
   for (auto& m : s->marker) if (m) (void)hipEventDestroy(m);
@@ -805,6 +827,8 @@ void rtc_scene_path_info(const rtc_scene* s, int32_t* choice, double* one_kernel
   if (one_kernel_ms) *one_kernel_ms = s ? s->tune_ms[0] : -1.0;
   if (wavefront_ms) *wavefront_ms = s ? s->tune_ms[1] : -1.0;
 }
+
+uint32_t rtc_scene_wavefront_lds_bytes(const rtc_scene* s) { return s ? rtc_wavefront_lds_bytes(s->d) : 0u; }
 
 void rtc_scene_accel_info(const rtc_scene* s, uint32_t* n_ops, uint32_t* n_bvh_nodes, uint32_t* n_mesh_tris, uint32_t* bvh_depth) {
   if (n_ops) *n_ops = s ? (uint32_t)s->d.n_ops : 0;

@@ -280,14 +280,12 @@ struct ProgramBuilder {
     if (!emit_linear(c0, end, depth, &hits)) return false;
     ops[at].b = (int32_t)ops.size();
     ops.push_back({OP_CSG_END, 0, 0, ci, -1, {0, 0, 0}});
-    if (hits > RTC_CSG_MAX_HITS) {
-      error = "a CSG group's subtree can produce more than RTC_CSG_MAX_HITS intersections (device buffer)";
-      status = RTC_ERR_UNSUPPORTED;
-      return false;
-    }
+    csg_max_hits = std::max(csg_max_hits, hits);  // beyond RTC_CSG_MAX_HITS the launches use a slab in device memory
     if (outer_hits) *outer_hits += hits;
     return true;
   }
+
+  int csg_max_hits = 0;
 
   // ---- whole-scene emission: aggregation groups are dissolved into per-primitive gates -------------------------------------
   std::vector<int32_t> prim_gcond;   // per primitive
@@ -457,7 +455,7 @@ struct HostArrays {
   std::vector<int32_t> mat_pattern;
   std::vector<DPat> pats;
   std::vector<double> lights;
-  int32_t n_lights = 0, all_cast_shadow = 1, bvh_depth = 0, bvh_stack = 8;
+  int32_t n_lights = 0, all_cast_shadow = 1, bvh_depth = 0, bvh_stack = 8, csg_max_hits = 0;
 
   // DScene.kops / kplanes (device_scene.h): a short, jump-free program travels in the kernel arguments.
   void fill_kernarg_program(DScene& d) const {
@@ -501,6 +499,8 @@ struct HostArrays {
     d.n_bvh = (int32_t)bvh.size(); d.n_items = (int32_t)items.size(); d.n_mtri = (int32_t)mtri_prim.size(); d.n_quirk = (int32_t)items.size();
     d.n_qitem = (int32_t)items.size(); d.n_qcell = (int32_t)qcell.size(); d.n_groups = (int32_t)(group_box.size() / 6); d.n_qgrids = (int32_t)qgrids.size();
     d.bvh_stack = bvh_stack;
+    d.csg_max_hits = csg_max_hits;
+    d.csg_slab = nullptr;
     d.has_mesh = 0;
     d.has_csg = 0;
     d.has_groups = 0;
@@ -605,6 +605,7 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
   H->bvh_frame = std::move(pb.bvh_frame);
   H->csg = std::move(pb.csg);
   H->bvh_depth = pb.max_depth;
+  H->csg_max_hits = pb.csg_max_hits;
   H->bvh_stack = std::max(8, pb.max_stack + 1);
   return RTC_OK;
 }

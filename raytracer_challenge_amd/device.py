@@ -45,18 +45,24 @@ UNIT_BYTES = {
 KERNARG_BYTES = {"node": 128, "plane": 48}
 
 
-def algorithmic_bytes(st: dict, path: str, n_prims: int = 0) -> dict:
+def algorithmic_bytes(st: dict, path: str, n_prims: int = 0, lds_tables: bool = False) -> dict:
     """Bytes one launch must move through the memory system by the accounting above, from the kernel's own work counters
     (rtc_stats of the counting variant).  `memory` is what roofline.achieved uses: never more than 4x the ideal
-    one-descent figure (guards against a bad accelerator)."""
+    one-descent figure (guards against a bad accelerator).  lds_tables: the wavefront traversal kernel keeps this
+    scene's nodes / records / mesh triangles in LDS (rtc_scene_wavefront_lds_bytes > 0): those fetches move no bytes through the
+    memory system either and are reported under `on_chip` beside the kernel-argument-resident ones."""
     import math
     wavefront = "wavefront" in path
+    lds = bool(lds_tables) and wavefront
+    node_b = UNIT_BYTES["node"] * (st["accel_nodes"] - st["accel_nodes_kernarg"])
+    tri_b = UNIT_BYTES["triangle"] * st["tri_tests"]
+    ana_b = UNIT_BYTES["analytic"] * (st["analytic_tests"] - st["analytic_tests_kernarg"])
     by_unit = {
         "ray": UNIT_BYTES["ray"] * st["unique_rays"] if wavefront else 0,
-        "node": UNIT_BYTES["node"] * (st["accel_nodes"] - st["accel_nodes_kernarg"]),
+        "node": 0 if lds else node_b,
         "group_box": UNIT_BYTES["group_box"] * st["group_tests"],
-        "triangle": UNIT_BYTES["triangle"] * st["tri_tests"],
-        "analytic": UNIT_BYTES["analytic"] * (st["analytic_tests"] - st["analytic_tests_kernarg"]),
+        "triangle": 0 if lds else tri_b,
+        "analytic": 0 if lds else ana_b,
         "pixel": UNIT_BYTES["pixel"] * st["pixels"],
     }
     counted = sum(by_unit.values())
@@ -64,6 +70,7 @@ def algorithmic_bytes(st: dict, path: str, n_prims: int = 0) -> dict:
     cap = 4 * ideal * st["unique_rays"] + UNIT_BYTES["pixel"] * st["pixels"]
     return {"memory": min(counted, cap), "counted": counted, "cap_4x_ideal": cap,
             "kernarg": KERNARG_BYTES["node"] * st["accel_nodes_kernarg"] + KERNARG_BYTES["plane"] * st["analytic_tests_kernarg"],
+            "lds": (node_b + tri_b + ana_b) if lds else 0,
             "by_unit": by_unit, "unit_bytes": UNIT_BYTES}
 
 
@@ -96,6 +103,8 @@ class DeviceRenderer:
         lib.rtc_last_error.restype = C.c_char_p
         lib.rtc_scene_device_bytes.restype = C.c_uint64
         lib.rtc_scene_device_bytes.argtypes = [C.c_void_p]
+        lib.rtc_scene_wavefront_lds_bytes.restype = C.c_uint32
+        lib.rtc_scene_wavefront_lds_bytes.argtypes = [C.c_void_p]
         lib.rtc_scene_accel_info.restype = None
         lib.rtc_scene_accel_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint32)] * 4
         self.backend, self.world, self.camera = backend, world, camera
@@ -169,4 +178,5 @@ class DeviceRenderer:
         a = [C.c_uint32(0) for _ in range(4)]
         self.backend.lib.rtc_scene_accel_info(self.scene, *[C.byref(x) for x in a])
         return {"scene_device_bytes": int(self.backend.lib.rtc_scene_device_bytes(self.scene)), "program_ops": a[0].value,
-                "bvh_nodes": a[1].value, "mesh_triangles": a[2].value, "bvh_depth": a[3].value}
+                "bvh_nodes": a[1].value, "mesh_triangles": a[2].value, "bvh_depth": a[3].value,
+                "wavefront_lds_bytes_per_block": int(self.backend.lib.rtc_scene_wavefront_lds_bytes(self.scene))}

@@ -33,6 +33,12 @@ static int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double*
   DStats st;
   std::memset(&st, 0, sizeof(st));
   unsigned n_launches = 1;
+  std::vector<DCsgHit> slab;
+  if (s->d.csg_max_hits > RTC_CSG_MAX_HITS) {  // as the product: rows per thread of the largest grid this call launches
+    const uint64_t threads = std::max<uint64_t>(((rtc_wavefront_work(cam, pm) + 63) / 64) * 64, 5 * 64);
+    slab.resize(threads * (uint64_t)s->d.csg_max_hits);
+    s->d.csg_slab = slab.data();
+  }
   const char* kv = std::getenv("RTC_KERNEL");
   if (kv && kv[0] == '4' && pm.n > 0) {  // wavefront path, host-allocated queues (grown on overflow, as the product does)
     const uint64_t n_work = rtc_wavefront_work(cam, pm);
@@ -137,6 +143,7 @@ void rtc_scene_path_info(const rtc_scene*, int32_t* choice, double* one_kernel_m
   if (one_kernel_ms) *one_kernel_ms = -1.0;
   if (wavefront_ms) *wavefront_ms = -1.0;
 }
+uint32_t rtc_scene_wavefront_lds_bytes(const rtc_scene*) { return 0; }
 void rtc_scene_accel_info(const rtc_scene* s, uint32_t* n_ops, uint32_t* n_bvh_nodes, uint32_t* n_mesh_tris, uint32_t* bvh_depth) {
   if (n_ops) *n_ops = (uint32_t)s->H.ops.size();
   if (n_bvh_nodes) *n_bvh_nodes = (uint32_t)s->H.bvh.size();

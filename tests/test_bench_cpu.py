@@ -47,8 +47,9 @@ def test_bench_line_contract_fields_single_rank():
     # the figure is recomputable from the line's own counters; kernel-argument-resident records are not in it
     want = sum(a["by_unit"].values())
     assert a["counted"] == want and a["memory"] == min(want, a["cap_4x_ideal"]) == r["algorithmic_bytes_per_launch"]
-    assert a["by_unit"]["node"] == 128 * (c["accel_nodes"] - c["accel_nodes_kernarg"])
-    assert a["by_unit"]["analytic"] == 128 * (c["analytic_tests"] - c["analytic_tests_kernarg"])
+    assert a["by_unit"]["node"] + (a["lds"] and 128 * (c["accel_nodes"] - c["accel_nodes_kernarg"])) == 128 * (c["accel_nodes"] - c["accel_nodes_kernarg"])
+    assert a["by_unit"]["analytic"] + (a["lds"] and 128 * (c["analytic_tests"] - c["analytic_tests_kernarg"])) == 128 * (c["analytic_tests"] - c["analytic_tests_kernarg"])
+    assert a["lds"] == 0      # the emulator reports no LDS-resident tables
     assert c["accel_nodes_kernarg"] > 0 and c["analytic_tests_kernarg"] > 0      # this scene's planes and BVH root travel in the kernel arguments
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] >= 1
     p = j["parity"]

@@ -173,11 +173,18 @@ def test_host_errors_and_flatten(emu):
     assert b.lib.rtw_world_flatten_counts(nw.handle, counts) == 0
     n_nodes, n_prims, n_xforms, n_limits, n_tris, n_materials, n_pats, n_lights = list(counts)
     assert (n_nodes, n_prims, n_xforms, n_tris, n_lights) == (244, 243, 4, 240, 2) and n_materials == 2
-    # a CSG subtree that can produce more intersections than the device buffer holds is refused loudly, not rendered wrongly
-    many = Element.composite(Matrix.id(), None, GroupKind.Aggregation, [Element.sphere(ShapeArgs(transform=Matrix.translation(0.1 * i, 0, 0))) for i in range(20)])
-    csg = World([PointLight(Color.white(), Vector.point(0, 5, -5))], [Element.composite(Matrix.id(), None, GroupKind.Difference, [many, Element.sphere()])])
-    with pytest.raises(rt.RtwError, match="RTC_CSG_MAX_HITS"):
-        emu.render(emu.build_world(csg), cam, 5)
+
+
+def test_csg_subtrees_beyond_the_per_lane_buffer(emu, orc):
+    """The reference's CSG lists are unbounded (src/shape.rs:248-269).  A subtree that can produce more intersections than the
+    per-lane buffer holds (32) is rendered through a slab in device memory, csg_max_hits rows per thread of the launch: 20 overlapping
+    spheres minus a sphere (42 possible intersections), on both device paths, against the oracle."""
+    many = Element.composite(Matrix.id(), None, GroupKind.Aggregation, [Element.sphere(ShapeArgs(transform=Matrix.translation(0.1 * i - 1.0, 0, 0))) for i in range(20)])
+    cut = Element.sphere(ShapeArgs(transform=Matrix.translation(0.3, 0.4, -0.6), material=Material(pattern=Pattern.plain(Color.new(0.9, 0.3, 0.2)), transparency=0.5, refractive_index=1.3)))
+    world = World([PointLight(Color.white(), Vector.point(0, 5, -5))], [Element.composite(Matrix.id(), None, GroupKind.Difference, [many, cut]), Element.plane(ShapeArgs(transform=Matrix.translation(0, -1.5, 0)))])
+    cam = Camera.new(48, 27, 0.9, Camera.transform(Vector.point(0, 1.0, -5), Vector.point(0, 0, 0), Vector.vector(0, 1, 0)))
+    assert_parity(emu, orc, world, cam, 5, label="CSG, 42 possible intersections")
+    assert_ray_parity(emu, orc, world, cases.edge_rays(512), 5, label="CSG beyond the buffer, edge rays")
 
 
 def test_no_device_fails_loudly():

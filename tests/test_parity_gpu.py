@@ -202,6 +202,20 @@ def test_hip_wavefront_allocation_failure_falls_back(hip, orc, monkeypatch):
     assert np.array_equal(ref[0], got[0])
 
 
+@pytest.mark.parametrize("path", ["1", "4"])
+def test_hip_csg_subtrees_beyond_the_per_lane_buffer(hip, orc, path, monkeypatch):
+    """CSG subtrees that can produce more than 32 intersections run through a slab in device memory (include/rtc.h): 20 overlapping
+    spheres minus a sphere, both device paths, against the oracle."""
+    from raytracer_challenge_amd.scene import Camera, Color, Element, GroupKind, Material, Matrix, Pattern, PointLight, ShapeArgs, Vector, World
+    monkeypatch.setenv("RTC_KERNEL", path)
+    many = Element.composite(Matrix.id(), None, GroupKind.Aggregation, [Element.sphere(ShapeArgs(transform=Matrix.translation(0.1 * i - 1.0, 0, 0))) for i in range(20)])
+    cut = Element.sphere(ShapeArgs(transform=Matrix.translation(0.3, 0.4, -0.6), material=Material(pattern=Pattern.plain(Color.new(0.9, 0.3, 0.2)), transparency=0.5, refractive_index=1.3)))
+    world = World([PointLight(Color.white(), Vector.point(0, 5, -5))], [Element.composite(Matrix.id(), None, GroupKind.Difference, [many, cut]), Element.plane(ShapeArgs(transform=Matrix.translation(0, -1.5, 0)))])
+    cam = Camera.new(160, 90, 0.9, Camera.transform(Vector.point(0, 1.0, -5), Vector.point(0, 0, 0), Vector.vector(0, 1, 0)))
+    assert_parity(hip, orc, world, cam, 5, label="CSG, 42 possible intersections, path " + path)
+    assert_ray_parity(hip, orc, world, cases.edge_rays(2048), 5, label="CSG beyond the buffer, edge rays")
+
+
 def test_hip_config4_teapot_high_4k_fuel8(hip, orc):
     """BASELINE configs[3] on one GPU: teapot_high.obj (6 320 smooth triangles), 3840x2160, fuel 8 — full frame on the HIP path,
     a strided sample against the oracle (which tests every triangle of the flat group, src/shape.rs:254-256)."""
