@@ -220,6 +220,11 @@ int rtc_scene_sync(rtc_scene*);
  * into mesh BVH leaves, deepest BVH (levels of 4-wide nodes).  Any pointer may be NULL. */
 void rtc_scene_accel_info(const rtc_scene*, uint32_t* n_ops, uint32_t* n_bvh_nodes, uint32_t* n_mesh_tris, uint32_t* bvh_depth);
 
+/* Number of this scene's mesh accelerators whose binary tree was built on the device (RTC_DEVICE_BVH=1: a linear BVH —
+ * Morton order + Karras' radix tree, csrc/bvh_device.hip — instead of the host's binned-SAH build; meshes of at least
+ * RTC_DEVICE_BVH_MIN = 4096 triangles).  The accelerator is results-neutral: pixels and hit records do not depend on it. */
+int rtc_scene_bvh_built_on_device(const rtc_scene*);
+
 /* Dynamic LDS (bytes per block) the wavefront traversal kernel uses for this scene: > 0 = the scene's accelerator nodes, intersection
  * records and mesh triangles are copied into every CU's LDS and walks read them there (small scenes: the tables and the traversal
  * stacks fit 160 KB); 0 = they are read from memory.  bench.py's byte accounting counts LDS-resident records as 0 bytes. */

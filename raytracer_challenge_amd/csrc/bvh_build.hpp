@@ -201,6 +201,9 @@ struct Builder {
   }
 };
 
+// A builder of the same binary tree on the device (bvh_device.hip: LBVH); returns the root or -1 (then the host builds).
+typedef int32_t (*DeviceBuildFn)(const std::vector<Item>& items, std::vector<DBvhNode>& nodes, std::vector<uint32_t>& order, uint32_t base, int leaf_max, double* frame);
+
 // Returns the root node index (always an inner node, so traversal can start from a node).
 // frame[4] receives the BVH's centre (x, y, z) and the inf-norm radius of its bounds around that centre.
 inline int32_t build(const std::vector<Item>& items, std::vector<DBvhNode>& nodes, std::vector<uint32_t>& order, uint32_t base, int* depth, bool median_only = false,

@@ -25,6 +25,7 @@ void rtc_launch_wavefront(const DScene& S, const DCamera& cam, const DPixelMap& 
 uint64_t rtc_wavefront_work(const DCamera& cam, const DPixelMap& pm);
 unsigned rtc_wavefront_grid(const DScene& S, int n_cu);
 unsigned rtc_wavefront_lds_bytes(const DScene& S);
+int32_t rtc_bvh_build_device(const std::vector<bvh::Item>& items, std::vector<DBvhNode>& n2, std::vector<uint32_t>& order, uint32_t base, int leaf_max, double* frame);
 
 static thread_local std::string g_rtc_err;
 static int rtc_fail(int code, const std::string& m) {
@@ -71,6 +72,7 @@ struct rtc_scene {
   unsigned wave_blocks = 0, shade_blocks = 0;
   unsigned wave_eighths = 9;  // queue capacity per level, in eighths of the launch's level-0 work ids
   int bvh_depth = 0;
+  int built_on_device = 0;  // mesh accelerators of this scene whose tree came from bvh_device.hip
   uint32_t n_bvh_nodes = 0, n_mesh_tris = 0;
 
   template <class T>
@@ -298,15 +300,18 @@ int rtc_device_count(void) {
 int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
   if (!desc || !out) return rtc_fail(RTC_ERR_INVALID, "NULL argument");
   *out = nullptr;
-  rtb::HostArrays H;
-  std::string err;
-  int rc = rtb::build_arrays(*desc, &H, &err);
-  if (rc != RTC_OK) return rtc_fail(rc, err);
-
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return rtc_fail(RTC_ERR_DEVICE, "no HIP device available (this library has no CPU path)");
   if (device < 0 || device >= ndev) return rtc_fail(RTC_ERR_DEVICE, "device index out of range");
   HIP_OK(hipSetDevice(device));
+  rtb::HostArrays H;
+  std::string err;
+  // RTC_DEVICE_BVH=1: mesh accelerators are built on the device (LBVH, bvh_device.hip) instead of the host's binned SAH: same
+  // pixels (the accelerator is results-neutral), faster build, slower trees
+  const char* dbe = std::getenv("RTC_DEVICE_BVH");
+  const bool device_bvh = dbe && dbe[0] == '1';
+  int rc = rtb::build_arrays(*desc, &H, &err, device_bvh ? rtc_bvh_build_device : nullptr);
+  if (rc != RTC_OK) return rtc_fail(rc, err);
 
   std::unique_ptr<rtc_scene> s(new rtc_scene());
   s->device = device;
@@ -352,6 +357,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     d.n_qitem = hv.n_qitem; d.n_qcell = hv.n_qcell; d.n_groups = hv.n_groups; d.n_qgrids = hv.n_qgrids;
   }
   s->bvh_depth = H.bvh_depth;
+  s->built_on_device = H.built_on_device;
   s->n_bvh_nodes = (uint32_t)H.bvh.size();
   s->n_mesh_tris = (uint32_t)H.mtri_prim.size();
   if (std::getenv("RTC_VERIFY_UPLOAD")) {  // debug aid: read every table back and compare with the host copy
@@ -827,6 +833,8 @@ void rtc_scene_path_info(const rtc_scene* s, int32_t* choice, double* one_kernel
   if (one_kernel_ms) *one_kernel_ms = s ? s->tune_ms[0] : -1.0;
   if (wavefront_ms) *wavefront_ms = s ? s->tune_ms[1] : -1.0;
 }
+
+int rtc_scene_bvh_built_on_device(const rtc_scene* s) { return s ? s->built_on_device : 0; }
 
 uint32_t rtc_scene_wavefront_lds_bytes(const rtc_scene* s) { return s ? rtc_wavefront_lds_bytes(s->d) : 0u; }
 

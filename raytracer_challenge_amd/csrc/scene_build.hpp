@@ -208,11 +208,17 @@ struct ProgramBuilder {
       bvh_nodes.resize(n0);
       order.resize(o0);
       auto t0_ = std::chrono::steady_clock::now();
-      int32_t root2 = bvh::build(items, n2, order, base, &depth2, attempt == 1, leaf_size(mesh), frame);
+      int32_t root2 = -1;
+      // large meshes can have their binary tree built on the device (LBVH, bvh_device.hip); the rest of the
+      // pipeline (4-wide collapse, stack bound, leaf packing) is shared, and a tree too deep for the stack falls to the median build
+      const bool on_device = attempt == 0 && mesh && device_build && items.size() >= device_build_min;
+      if (on_device) root2 = device_build(items, n2, order, base, leaf_size(mesh), frame);
+      if (root2 >= 0) built_on_device++;
+      else { n2.clear(); order.resize(o0); root2 = bvh::build(items, n2, order, base, &depth2, attempt == 1, leaf_size(mesh), frame); }
       auto t1_ = std::chrono::steady_clock::now();
       root = bvh::collapse4(n2, root2, bvh_nodes, &depth, &need);
       if (std::getenv("RTC_TIMING") && items.size() > 100000)
-        std::fprintf(stderr, "[rtc-timing]   SAH build %.3f s, collapse4 %.3f s (%zu items)\n", std::chrono::duration<double>(t1_ - t0_).count(),
+        std::fprintf(stderr, "[rtc-timing]   %s build %.3f s, collapse4 %.3f s (%zu items)\n", on_device && built_on_device ? "device LBVH" : "host SAH", std::chrono::duration<double>(t1_ - t0_).count(),
                      std::chrono::duration<double>(std::chrono::steady_clock::now() - t1_).count(), items.size());
       if (need <= RTC_BVH_STACK - 1) break;
     }
@@ -286,6 +292,9 @@ struct ProgramBuilder {
   }
 
   int csg_max_hits = 0;
+  bvh::DeviceBuildFn device_build = nullptr;  // set by rtc_scene_create when the accelerator is to be built on the device
+  size_t device_build_min = 4096;
+  int built_on_device = 0;
 
   // ---- whole-scene emission: aggregation groups are dissolved into per-primitive gates -------------------------------------
   std::vector<int32_t> prim_gcond;   // per primitive
@@ -455,7 +464,7 @@ struct HostArrays {
   std::vector<int32_t> mat_pattern;
   std::vector<DPat> pats;
   std::vector<double> lights;
-  int32_t n_lights = 0, all_cast_shadow = 1, bvh_depth = 0, bvh_stack = 8, csg_max_hits = 0;
+  int32_t n_lights = 0, all_cast_shadow = 1, bvh_depth = 0, bvh_stack = 8, csg_max_hits = 0, built_on_device = 0;
 
   // DScene.kops / kplanes (device_scene.h): a short, jump-free program travels in the kernel arguments.
   void fill_kernarg_program(DScene& d) const {
@@ -522,7 +531,7 @@ struct HostArrays {
 };
 
 // desc -> arrays.  Returns an RTC_* status; message in *err.
-inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err) {
+inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err, bvh::DeviceBuildFn device_build = nullptr) {
   int rc = validate(D, err);
   if (rc != RTC_OK) return rc;
   if (D.n_lights > 64) { *err = "more than 64 lights"; return RTC_ERR_INVALID; }
@@ -536,6 +545,8 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
   };
   lap("validate");
   ProgramBuilder pb{D};
+  pb.device_build = device_build;
+  if (const char* e = std::getenv("RTC_DEVICE_BVH_MIN")) pb.device_build_min = (size_t)std::strtoull(e, nullptr, 10);
   if (!pb.emit(0, D.n_nodes) || pb.status != RTC_OK) { *err = pb.error; return pb.status != RTC_OK ? pb.status : RTC_ERR_INVALID; }
   lap("program + BVH build");
   H->prims.resize(D.n_prims);
@@ -606,6 +617,7 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
   H->csg = std::move(pb.csg);
   H->bvh_depth = pb.max_depth;
   H->csg_max_hits = pb.csg_max_hits;
+  H->built_on_device = pb.built_on_device;
   H->bvh_stack = std::max(8, pb.max_stack + 1);
   return RTC_OK;
 }

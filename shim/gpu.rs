@@ -384,7 +384,7 @@ fn rtc_camera(camera: &Camera) -> RtcCamera {
 /// `Image::par_render`'s pixels on the MI355X: row-major `Vec<Color>` of `hsize * vsize`, as the reference collects them
 /// (src/image.rs:66-74).  `fuel` is the reference's compile-time `FUEL` (src/config.rs:2).  All visible devices are used
 /// (rows interleaved by device, gathered to the first); `Err(code == RTC_ERR_UNSUPPORTED)` = a scene beyond a device limit
-/// (an oversized CSG subtree): keep the CPU body for that scene.
+/// (CSG groups nested deeper than 8; an intersection slab beyond the memory budget): keep the CPU body for that scene.
 pub fn render(camera: &Camera, world: &World, fuel: i32) -> Result<Vec<Color>, GpuError> {
     let flat = Flat::from_world(world);
     let desc = flat.desc();

@@ -144,6 +144,7 @@ void rtc_scene_path_info(const rtc_scene*, int32_t* choice, double* one_kernel_m
   if (wavefront_ms) *wavefront_ms = -1.0;
 }
 uint32_t rtc_scene_wavefront_lds_bytes(const rtc_scene*) { return 0; }
+int rtc_scene_bvh_built_on_device(const rtc_scene*) { return 0; }
 void rtc_scene_accel_info(const rtc_scene* s, uint32_t* n_ops, uint32_t* n_bvh_nodes, uint32_t* n_mesh_tris, uint32_t* bvh_depth) {
   if (n_ops) *n_ops = (uint32_t)s->H.ops.size();
   if (n_bvh_nodes) *n_bvh_nodes = (uint32_t)s->H.bvh.size();
