@@ -340,7 +340,7 @@ def measure(args, rtm, dist, workload, fuel, steps, warmup, F, rank, world_size,
             "kernel_ms_avg": seq_ms, "kernel_ms_measured_over": "%d sequential launches after the timed region, HIP events on the scene's stream" % n_seq,
             "algorithmic_bytes_per_launch": alg["memory"], "algorithmic_bytes": alg, "path": path,
             "counters_rank0": {k: cst[k] for k in ("pixels", "unique_rays", "rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "rays_container", "accel_nodes",
-                                                   "accel_nodes_kernarg", "group_tests", "tri_tests", "analytic_tests", "analytic_tests_kernarg")},
+                                                   "accel_nodes_kernarg", "group_tests", "tri_tests", "analytic_tests", "analytic_tests_kernarg", "light_grid_cells")},
             "note": "not the binding limit: the scene (%d B) is L2 / Infinity-Cache resident and most algorithmic bytes are served on chip; "
                     "hbm_traffic_frac is the real HBM share, `valu` the pipe that binds" % dr.info()["scene_device_bytes"]}
     res["roofline"] = roof

@@ -145,6 +145,8 @@ typedef struct rtc_stats {
   uint32_t _pad;
   uint64_t accel_nodes_kernarg;    /* of accel_nodes: root nodes read from the kernel arguments           */
   uint64_t analytic_tests_kernarg; /* of analytic_tests: plane records read from the kernel arguments     */
+  uint64_t light_grid_cells;       /* light-grid cells looked up by shadow rays, each instead of a BVH walk (8 B of
+                                      offsets + 4 B per candidate)                                         */
 } rtc_stats;
 
 const char* rtc_last_error(void);

@@ -11,7 +11,8 @@
 //   (OP_MESH / OP_BVH: c = index of the BVH's frame in bvh_frame)
 //   OP_MESH   a = BVH root, b = xform index: triangles sharing one matrix; ray transformed once, BVH in
 //             object space, leaves index the packed triangle arrays (mtri / mtri_prim)
-//   OP_BVH    a = BVH root: world-space BVH over analytic primitives; leaves index item_prim
+//   OP_BVH    a = BVH root: world-space BVH over analytic primitives; leaves index item_prim; b = 0 or 1 + the index in qgrids of
+//             the first of n_lights light grids, which hand a shadow ray its candidates without a walk (RTC_LIGHT_CELL_WALK below)
 //   OP_QUIRK  a = first, b = count in quirk_prim: the cubes and cones of the preceding OP_BVH, scanned linearly for
 //             rays in the state where the reference reports intersections outside the primitive's bounds
 //   OP_QGRID  a = index into qgrids: the same scan, culled by ray DIRECTION: whether a ray is a quirk ray for a cube /
@@ -69,6 +70,10 @@ struct DQuirkGrid {
   int32_t n, cell_off, lin_first, lin_count;
 };
 #define RTC_QGRID_MIN_LEN 0.05
+// Light grids (scene_build.hpp build_light_grids; OP_BVH b = 1 + index of light 0's grid in qgrids, 0 = none): the same cell function;
+// a cell's items are the BVH leaf references of its candidates, or this one value: too many candidates, walk the BVH.
+#define RTC_LIGHT_CELL_WALK 0x7fffffff
+struct alignas(8) DLightItem { int32_t ref; float dmin; };  // dmin: no point of the candidate's bounds is nearer to the light (nearest first)
 
 // Kernel-argument copy of what every ray reads first of a BVH: its frame, (meshes) the world -> object matrix, the root node.
 #define RTC_KAUX 3
@@ -153,6 +158,7 @@ struct DScene {
   int32_t has_csg;           // 1: the program contains an OP_CSG
   int32_t has_groups;        // 0: no gates; 1: only OP_MESH / OP_CSG ops are gated; 2: individual primitives are gated
   int32_t csg_max_hits;      // most intersections one top-level CSG subtree can produce
+  int32_t light_grid_first;  // 0 or 1 + index in qgrids of light 0's light grid (= the b of the program's OP_BVH)
   int32_t has_recs;          // 1: some op reads intersection records (pisect): analytic BVH, quirk scans, primitives outside the kernel arguments
   // Kernel-argument copy of a short traversal program (kernargs are read with scalar loads: the op fetch and the plane
   // records stop being per-lane vector loads on every ray's dependency chain).  Used when n_kops > 0: the whole program
@@ -190,6 +196,7 @@ struct DStats {  // device-side counters (atomically accumulated per wave)
   unsigned long long accel_nodes, group_tests, tri_tests, analytic_tests;
   unsigned long long knodes;    // of accel_nodes: BVH root nodes read from the kernel arguments (scalar loads, no memory traffic)
   unsigned long long kplanes;   // of analytic_tests: plane records read from the kernel arguments
+  unsigned long long light_cells;  // light-grid cells looked up by shadow rays (each in place of a BVH walk)
   unsigned long long diag[64];  // RTC_DIAG builds only: region cycles / lane-utilisation sums (scripts/diag_report.py)
   // sticky error state: accumulated over every launch since the last rtc_scene_check() / synchronous read-back, which clear it
   unsigned long long nan_ts;       // NaN intersection t's seen (-> RTC_ERR_NAN)

@@ -67,6 +67,9 @@
 #define RTC_WF_LANES 64u
 #endif
 #define DINF (__builtin_inf())
+#ifndef RTC_PROBE
+#define RTC_PROBE 0  // cost probes (scripts/build_variant.sh ... -DRTC_PROBE=<bits>): a section runs twice, pixels unchanged. 1 planes, 2 quirk grid, 4 node steps, 8 Phong, 16 analytic leaf tests
+#endif
 // RTC_LAUNDER(x): the compiler may not assume it knows x's value any more.  Used on a work item's index right after a traversal:
 // without it every output address derived from the index before the traversal (hipcc computes them all up front) stays live
 // across it, and at a 128-register budget that meant ~60 dwords spilled to scratch and reloaded per ray.
@@ -95,6 +98,8 @@ struct Trav {
   int best_prim, best_k, best_klast;
   int shadowed;
   int unordered;  // any-hit pass that skips the nearest-first ordering of a node's children
+  int light;      // shadow passes: index of the light the ray runs towards (its light grid may stand in for the BVH walk), the ray's
+                  // length in c1_t; else -1
   double c1_t, c2_t;
   int c1_prim, c2_prim;
   // per-ray cache of the reference's group box tests (groups 0..63): bit set in g_known once evaluated, in g_pass if it hit
@@ -104,6 +109,7 @@ struct Trav {
 struct Counters {
   unsigned int accel_nodes, group_tests, tri_tests, analytic_tests, nan_ts;
   unsigned int knodes, kplanes;  // of accel_nodes / analytic_tests: records that came from the kernel arguments (no memory traffic)
+  unsigned int light_cells;      // light-grid cells looked up (each in place of a BVH walk)
 };
 
 // ---- diagnostics (RTC_DIAG builds only; the shipped kernel compiles these to nothing) ----------------------------------
@@ -116,7 +122,7 @@ __shared__ unsigned long long s_diag[64];
 #define DIAG_REGION(r) do { unsigned long long t1_ = __builtin_amdgcn_s_memtime(); atomicAdd(&s_diag[2 * (r)], t1_ - diag_t0_); atomicAdd(&s_diag[2 * (r) + 1], 1ull); diag_t0_ = t1_; } while (0)
 #define DIAG_SPAN_BEGIN() unsigned long long span_t0_ = __builtin_amdgcn_s_memtime()
 #define DIAG_SPAN_END(r) do { atomicAdd(&s_diag[2 * (r)], __builtin_amdgcn_s_memtime() - span_t0_); atomicAdd(&s_diag[2 * (r) + 1], 1ull); } while (0)
-#define DIAG_LOOP(j) do { unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) { s_diag[16 + 2 * (j)] += (unsigned long long)__popcll(m_); s_diag[16 + 2 * (j) + 1] += 1ull; } } while (0)
+#define DIAG_LOOP(j) do { unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) { atomicAdd(&s_diag[16 + 2 * (j)], (unsigned long long)__popcll(m_)); atomicAdd(&s_diag[16 + 2 * (j) + 1], 1ull); } } while (0)
 #else
 #define DIAG_T0() do {} while (0)
 #define DIAG_REGION(r) do {} while (0)
@@ -431,19 +437,18 @@ __device__ __forceinline__ void visit_prim(const DScene& S, int prim, const Ray&
   double t[4], u = 0.0, v = 0.0;
   if (P.geom >= 5) C.tri_tests++; else C.analytic_tests++;
   int n = prim_hits(S, P, o, t, u, v);
+  if (n > 0) { DIAG_LOOP(23); }
   accept(T, C, prim, n, t);
 }
 
 // Direction-grid culled quirk scan (device_scene.h OP_QGRID).  The cell lookup must mirror build_quirk_grid().
-template <int FEAT, bool LDSC = false>
-__device__ __forceinline__ void quirk_grid_scan(const DScene& S, const DQuirkGrid G, const Ray& r, Trav& T, Counters& C, const LdsScene& L = LdsScene{}) {
-  DIAG_LOOP(21);
+// The cell of a direction grid (quirk grids, light grids: cube map, n x n cells per face) a ray's direction falls into -> its item
+// range [b, e) of qitem; false: the direction is too short or not finite for the builders' bounds (they assume length >=
+// RTC_QGRID_MIN_LEN), the caller takes its fallback.  Must mirror build_quirk_grid() / build_light_grids().
+__device__ __forceinline__ bool dir_grid_cell(const DScene& S, const DQuirkGrid G, const Ray& r, unsigned& b, unsigned& e) {
   double ax = fabs(r.dx), ay = fabs(r.dy), az = fabs(r.dz);
   double len2 = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
-  if (!(len2 >= RTC_QGRID_MIN_LEN * RTC_QGRID_MIN_LEN) || !(len2 < DINF)) {
-    for (int i = G.lin_first; i < G.lin_first + G.lin_count; i++) visit_prim<FEAT, LDSC>(S, S.quirk_prim[i], r, T, C, 2, L);
-    return;
-  }
+  if (!(len2 >= RTC_QGRID_MIN_LEN * RTC_QGRID_MIN_LEN) || !(len2 < DINF)) return false;
   int face;
   double u, v;
   if (ax >= ay && ax >= az) { face = r.dx > 0.0 ? 0 : 1; u = r.dy / ax; v = r.dz / ax; }
@@ -453,8 +458,73 @@ __device__ __forceinline__ void quirk_grid_scan(const DScene& S, const DQuirkGri
   iu = iu < 0 ? 0 : (iu >= G.n ? G.n - 1 : iu);
   iv = iv < 0 ? 0 : (iv >= G.n ? G.n - 1 : iv);
   int cell = G.cell_off + (face * G.n + iv) * G.n + iu;
-  unsigned b = S.qcell[cell], e = S.qcell[cell + 1];
+  b = S.qcell[cell]; e = S.qcell[cell + 1];
+  return true;
+}
+
+template <int FEAT, bool LDSC = false>
+__device__ __forceinline__ void quirk_grid_scan(const DScene& S, const DQuirkGrid G, const Ray& r, Trav& T, Counters& C, const LdsScene& L = LdsScene{}) {
+  DIAG_LOOP(21);
+  unsigned b, e;
+  if (!dir_grid_cell(S, G, r, b, e)) {
+    for (int i = G.lin_first; i < G.lin_first + G.lin_count; i++) visit_prim<FEAT, LDSC>(S, S.quirk_prim[i], r, T, C, 2, L);
+    return;
+  }
   for (unsigned i = b; i < e; i++) visit_prim<FEAT, LDSC>(S, S.qitem[i], r, T, C, 2, L);
+}
+
+// Light grids (scene_build.hpp build_light_grids): a shadow ray towards light T.light takes the candidates of its direction's cell
+// instead of walking the analytic BVH.  The lookup is two dependent fetches from memory (cell range, then items), so a traversal
+// starts it before its first op (light_grid_fetch) and only collects the answer at the OP_BVH (light_grid_candidates): the plane
+// tests in between hide the latency.
+struct LightCell {
+  int state;            // 0: no grid / not a shadow ray / direction not covered -> ordinary walk; 1: range and first items fetched
+  unsigned b, e;        // item range of the cell (qitem, pairs)
+  DLightItem i0, i1;    // its first two items (most cells hold no more)
+};
+#define RTC_WALK_END ((int)0x80000000)
+template <int MODE>
+__device__ __forceinline__ LightCell light_grid_fetch(const DScene& S, const Ray& r, const Trav& T) {
+  LightCell c;
+  c.state = 0; c.b = 0; c.e = 0;
+  c.i0.ref = RTC_WALK_END; c.i0.dmin = 0.0f; c.i1 = c.i0;
+  if (MODE == MODE_CLOSEST || MODE == MODE_CONTAINERS) return c;
+  if (S.light_grid_first <= 0 || T.light < 0) return c;
+  if (!dir_grid_cell(S, S.qgrids[S.light_grid_first - 1 + T.light], r, c.b, c.e)) return c;
+  c.state = 1;
+  if (c.b < c.e) c.i0 = *(const DLightItem*)(S.qitem + c.b);  // (8-byte aligned by the builder)
+  if (c.b + 2 < c.e) c.i1 = *(const DLightItem*)(S.qitem + c.b + 2);
+  return c;
+}
+// The cell's candidates — leaf references, as the BVH's own — go where the walk would have put them: the first becomes `cur`, the
+// others wait on the stack.  Items: {reference, f32 lower bound of the candidate's distance from the light}, nearest first: a candidate
+// farther from the light than the ray's origin (T.c1_t = the ray's length, slightly raised in f32) lies behind the origin, it and all
+// after it are skipped.  true: (cur, sp) are set (cur = RTC_WALK_END: nothing to test); false: the ordinary walk.
+__device__ __forceinline__ bool light_grid_candidates(const DScene& S, const LightCell& c, const Trav& T, Counters& C, int& cur, int& sp, int* __restrict__ stack, int stride) {
+  if (c.state == 0) return false;
+  const float reach = (float)T.c1_t * 1.000001f + 1e-30f;
+  int first = RTC_WALK_END;
+  int n = 0;
+  if (c.b < c.e) {
+    if (c.i0.ref == RTC_LIGHT_CELL_WALK) return false;
+    if (c.i0.dmin <= reach) {
+      first = c.i0.ref; n = 1;
+      if (c.b + 2 < c.e && c.i1.dmin <= reach) {
+        stack[0] = c.i1.ref; n = 2;
+        for (unsigned i = c.b + 4; i < c.e; i += 2) {
+          const DLightItem it = *(const DLightItem*)(S.qitem + i);
+          if (!(it.dmin <= reach)) break;
+          stack[(n - 1) * stride] = it.ref;
+          n++;
+        }
+      }
+    }
+  }
+  sp = n > 0 ? n - 1 : 0;
+  C.light_cells++;
+  DIAG_LOOP(22);
+  cur = first;
+  return true;
 }
 
 // ---- accelerator -------------------------------------------------------------------------------------
@@ -464,12 +534,16 @@ __device__ __forceinline__ void quirk_grid_scan(const DScene& S, const DQuirkGri
 //   eps = 2^-20 (|of|_inf + R)            R = radius of the BVH around c: >= 16x every f32 rounding error of the test,
 //                                         each of which is bounded by 2^-23 times a coordinate or a distance travelled
 //   every box is inflated by eps by testing its low faces against of + eps and its high faces against of - eps,
-//   and the pass's t interval is widened by 2^-18 relative.
+//   and the pass's t interval is widened by 2^-18 relative.  A face's distance is ONE fused multiply-add, face * i - (of +- eps) * i
+//   with i = 1 / direction: the product is rounded once per ray (2^-24 |of * i|, an eighth of what eps moves the face by), the fma
+//   once per face as a multiplication would be.  |i| is capped at 1e30 (a zero direction component: +-1e30 decides inside /
+//   outside the slab like +-inf would, but inf - inf would be NaN); a product that still overflows makes a NaN, which the
+//   min / max ignore: the box is taken.
 // So a box is rejected only if the f64 ray misses the box inflated by ~15 eps or its [tn, tf] misses [t_lo, t_hi]; NaN
 // (0 * inf) operands are ignored by fminf/fmaxf exactly as in the f64 version.  A ray whose origin does not fit f32
 // relative to c takes every box (id = 0 makes every slab interval [0, 0]).
 struct Frame32 {
-  float olx, oly, olz, ohx, ohy, ohz, ix, iy, iz;
+  float olx, oly, olz, ohx, ohy, ohz, ix, iy, iz;  // ol / oh: (origin + eps) * i and (origin - eps) * i, see make_frame
 };
 __device__ __forceinline__ void make_frame(const double* __restrict__ fr, const Ray& o, Frame32& f) {
   float ox = (float)(o.ox - fr[0]), oy = (float)(o.oy - fr[1]), oz = (float)(o.oz - fr[2]);
@@ -483,31 +557,25 @@ __device__ __forceinline__ void make_frame(const double* __restrict__ fr, const 
   f.olx = ox + eps; f.oly = oy + eps; f.olz = oz + eps;
   f.ohx = ox - eps; f.ohy = oy - eps; f.ohz = oz - eps;
   f.ix = 1.0f / (float)o.dx; f.iy = 1.0f / (float)o.dy; f.iz = 1.0f / (float)o.dz;
+  f.ix = f.ix > 1e30f ? 1e30f : (f.ix < -1e30f ? -1e30f : f.ix);  // (a NaN stays a NaN: every box is taken, as before)
+  f.iy = f.iy > 1e30f ? 1e30f : (f.iy < -1e30f ? -1e30f : f.iy);
+  f.iz = f.iz > 1e30f ? 1e30f : (f.iz < -1e30f ? -1e30f : f.iz);
+  f.olx *= f.ix; f.oly *= f.iy; f.olz *= f.iz;
+  f.ohx *= f.ix; f.ohy *= f.iy; f.ohz *= f.iz;
 }
 __device__ __forceinline__ void t_interval32(const Trav& T, float& lo, float& hi) {
   const double SL = 3.814697265625e-06;  // 2^-18
   lo = (T.tlo == -DINF) ? -__builtin_inff() : (float)(T.tlo - SL * fmax(fabs(T.tlo), 1.0));
   hi = (T.thi == DINF) ? __builtin_inff() : (float)(T.thi + SL * fmax(fabs(T.thi), 1.0));
 }
-__device__ __forceinline__ bool slab32(const float* __restrict__ lo, const float* __restrict__ hi, const Frame32& f, float tlo, float thi, float& tn_out) {
-  float t0 = (lo[0] - f.olx) * f.ix, t1 = (hi[0] - f.ohx) * f.ix;
-  float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
-  t0 = (lo[1] - f.oly) * f.iy; t1 = (hi[1] - f.ohy) * f.iy;
-  tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
-  t0 = (lo[2] - f.olz) * f.iz; t1 = (hi[2] - f.ohz) * f.iz;
-  tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
-  tn_out = tn;
-  return fmaxf(tn, tlo) <= fminf(tf, thi) && lo[0] <= hi[0];
-}
-
 __device__ __forceinline__ float4 ld4(const float* p) { float4 v; __builtin_memcpy(&v, p, 16); return v; }
 __device__ __forceinline__ int4 ld4(const int32_t* p) { int4 v; __builtin_memcpy(&v, p, 16); return v; }
 __device__ __forceinline__ bool slab32c(float lx, float ly, float lz, float hx, float hy, float hz, const Frame32& f, float tlo, float thi, float& tn_out) {
-  float t0 = (lx - f.olx) * f.ix, t1 = (hx - f.ohx) * f.ix;
+  float t0 = __builtin_fmaf(lx, f.ix, -f.olx), t1 = __builtin_fmaf(hx, f.ix, -f.ohx);
   float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
-  t0 = (ly - f.oly) * f.iy; t1 = (hy - f.ohy) * f.iy;
+  t0 = __builtin_fmaf(ly, f.iy, -f.oly); t1 = __builtin_fmaf(hy, f.iy, -f.ohy);
   tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
-  t0 = (lz - f.olz) * f.iz; t1 = (hz - f.ohz) * f.iz;
+  t0 = __builtin_fmaf(lz, f.iz, -f.olz); t1 = __builtin_fmaf(hz, f.iz, -f.ohz);
   tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
   tn_out = tn;
   return fmaxf(tn, tlo) <= fminf(tf, thi) && lx <= hx;
@@ -515,7 +583,6 @@ __device__ __forceinline__ bool slab32c(float lx, float ly, float lz, float hx, 
 
 // One inner-node step of the walk: the node's four child boxes against the ray; hits ordered nearest first, the nearest
 // becomes `cur`, the others are stacked; no hit pops (or ends the walk: cur = END).
-#define RTC_WALK_END ((int)0x80000000)
 __device__ __forceinline__ void node_step(const float4 lox, const float4 loy, const float4 loz, const float4 hix, const float4 hiy, const float4 hiz, const int4 cc,
                                           const Frame32& F, float lo, float hi, int& cur, int& sp, int* __restrict__ stack, int stride, bool any_hit) {
   const float FINF = __builtin_inff();
@@ -600,6 +667,12 @@ __device__ __forceinline__ void walk_loop(const DScene& S, const bool mesh, int 
         lox = ld4(N->lox); loy = ld4(N->loy); loz = ld4(N->loz); hix = ld4(N->hix); hiy = ld4(N->hiy); hiz = ld4(N->hiz);
         cc = ld4(N->c);
       }
+      if (RTC_PROBE & 4) {  // cost probe: the node step twice (same pushes, same result)
+        const int cur0 = cur, sp0 = sp;
+        node_step(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride, any_hit);
+        RTC_LAUNDER(lox.x);
+        cur = cur0; sp = sp0;
+      }
       node_step(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride, any_hit);
     }
     if (cur == END) return;
@@ -620,7 +693,12 @@ __device__ __forceinline__ void walk_loop(const DScene& S, const bool mesh, int 
         }
       } else {
         DIAG_LOOP(1);
-        visit_prim<FEAT, LDSC>(S, first, world, T, C, 1, L);  // analytic leaf = one primitive, named by the ref itself
+#pragma unroll 1
+        for (int rep_ = 0; rep_ < ((RTC_PROBE & 16) ? 2 : 1); rep_++) {
+          Ray w2 = world;
+          if (RTC_PROBE & 16) RTC_LAUNDER(w2.ox);
+          visit_prim<FEAT, LDSC>(S, first, w2, T, C, 1, L);  // analytic leaf = one primitive, named by the ref itself
+        }
       }
       DIAG_SPAN_END(6);
       if (T.mode == MODE_SHADOW_ANY && T.shadowed) return;
@@ -717,6 +795,7 @@ __device__ __noinline__ int csg_eval(const DScene& S, int pc, const Ray& r, Trav
 template <int FEAT, bool KOPS, int MODE = -1, bool LDSC = false>
 __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T, Counters& C, int* __restrict__ stack, int stride, const LdsScene& L = LdsScene{}) {
   if (MODE >= 0) T.mode = MODE;
+  const LightCell lcell = light_grid_fetch<MODE>(S, r, T);
   if (KOPS) {
     for (int pc = 0; pc < S.n_kops; pc++) {
       DIAG_LOOP(2);
@@ -733,11 +812,16 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
           C.analytic_tests++;
           C.kplanes++;
           DIAG_LOOP(8);
-          double oy = P.row[0] * r.ox + P.row[1] * r.oy + P.row[2] * r.oz + P.row[3] * 1.0;
-          double dy = P.row[0] * r.dx + P.row[1] * r.dy + P.row[2] * r.dz + P.row[3] * 0.0;
-          if (!(fabs(dy - 0.0) < EPS) && !plane_behind(T, oy, dy)) {
-            double t = -oy / dy;
-            accept(T, C, P.prim, 1, &t);
+          for (int rep_ = 0; rep_ < ((RTC_PROBE & 1) ? 2 : 1); rep_++) {
+            double rox = r.ox;
+            if (RTC_PROBE & 1) RTC_LAUNDER(rox);
+            double oy = P.row[0] * rox + P.row[1] * r.oy + P.row[2] * r.oz + P.row[3] * 1.0;
+            double dy = P.row[0] * r.dx + P.row[1] * r.dy + P.row[2] * r.dz + P.row[3] * 0.0;
+            if (RTC_PROBE & 1) RTC_LAUNDER(dy);
+            if (!(fabs(dy - 0.0) < EPS) && !plane_behind(T, oy, dy)) {
+              double t = -oy / dy;
+              accept(T, C, P.prim, 1, &t);
+            }
           }
         } else {
           visit_prim<FEAT, LDSC>(S, op.a, r, T, C, 0, L);
@@ -746,13 +830,19 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
         for (int i = op.a; i < op.a + op.b; i++) visit_prim<FEAT, LDSC>(S, S.quirk_prim[i], r, T, C, 2, L);
       } else if (op.op == OP_QGRID) {
         DIAG_SPAN_BEGIN();
-        quirk_grid_scan<FEAT, LDSC>(S, op.pad[0] >= 0 ? S.kqgrid : S.qgrids[op.a], r, T, C, L);
+        for (int rep_ = 0; rep_ < ((RTC_PROBE & 2) ? 2 : 1); rep_++) {
+          Ray rr = r;
+          if (RTC_PROBE & 2) RTC_LAUNDER(rr.dx);
+          quirk_grid_scan<FEAT, LDSC>(S, op.pad[0] >= 0 ? S.kqgrid : S.qgrids[op.a], rr, T, C, L);
+        }
         DIAG_SPAN_END(4);
       } else if (!mesh || FEAT == 0 || op.g < 0 || groups_pass<false>(S, op.g, r, T, C)) {  // OP_MESH / OP_BVH
         walk = true;
         cur = op.a;
-        DIAG_LOOP(16);
-        if (op.pad[0] >= 0) {
+        if (!mesh && light_grid_candidates(S, lcell, T, C, cur, sp, stack, stride)) {
+          walk = cur != RTC_WALK_END;
+        } else if (op.pad[0] >= 0) {
+          DIAG_LOOP(16);
           const DKAux& A = S.kaux[op.pad[0]];
           if (mesh) o = to_object(A.xf, r);
           make_frame(A.frame, o, F);
@@ -775,6 +865,7 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
     DIAG_LOOP(2);
     DOp op = S.ops[pc];
     bool walk = false, mesh = false;
+    int cur = 0, sp = 0;
     Frame32 F;
     Ray o = r;
     if (op.op == OP_PRIM) {
@@ -796,14 +887,19 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
       else pc = csg_eval(S, pc, r, T, C);
     } else {  // OP_MESH / OP_BVH
       mesh = op.op == OP_MESH;
+      cur = op.a; sp = 0;
       if (!mesh || FEAT == 0 || op.g < 0 || groups_pass<(FEAT >= 2)>(S, op.g, r, T, C)) {
         walk = true;
-        if (mesh) o = to_object(S.xf_inv + 12 * op.b, r);
-        make_frame(S.bvh_frame + 4 * op.c, o, F);
+        if (!mesh && light_grid_candidates(S, lcell, T, C, cur, sp, stack, stride)) {
+          walk = cur != RTC_WALK_END;
+        } else {
+          if (mesh) o = to_object(S.xf_inv + 12 * op.b, r);
+          make_frame(S.bvh_frame + 4 * op.c, o, F);
+        }
       }
       pc++;
     }
-    if (walk) walk_loop<FEAT, LDSC>(S, mesh, op.a, 0, F, r, o, T, C, stack, stride, L);
+    if (walk) walk_loop<FEAT, LDSC>(S, mesh, cur, sp, F, r, o, T, C, stack, stride, L);
     if (T.mode == MODE_SHADOW_ANY && T.shadowed) return;
   }
 }
@@ -1093,6 +1189,7 @@ __device__ __forceinline__ void reset_closest(Trav& T, int mode) {
   T.best_t = DINF; T.best_prim = 0x7fffffff; T.best_k = 0; T.best_klast = 0;
   T.shadowed = 0;
   T.unordered = 0;
+  T.light = -1;
   T.c1_t = 0.0; T.c2_t = 0.0; T.c1_prim = -1; T.c2_prim = -1;
   T.g_known = 0ull; T.g_pass = 0ull;
 }
@@ -1192,7 +1289,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, WAVES ? WAVES : ((FEAT >= 2 && RTC_
   RTC_LDS_STACK(lds_stack);
   int* stack = lds_stack + threadIdx.x;
   const int stride = RTC_BLOCK;
-  Counters C = {0, 0, 0, 0, 0, 0, 0};
+  Counters C = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned n_primary = 0, n_shadow = 0, n_reflect = 0, n_refract = 0, n_container = 0;
   const WorkMap wm = make_workmap(pm, cam);
 #ifdef RTC_DIAG
@@ -1286,6 +1383,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, WAVES ? WAVES : ((FEAT >= 2 && RTC_
           Trav Sh;
           reset_closest(Sh, S.all_cast_shadow ? MODE_SHADOW_ANY : MODE_SHADOW_CLOSEST);
           if (S.all_cast_shadow) Sh.thi = distance;
+          Sh.light = l; Sh.c1_t = distance;
           DIAG_T0();
           traverse<FEAT, KOPS>(S, sray, Sh, C, stack, stride);
           DIAG_REGION(3);
@@ -1390,6 +1488,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, WAVES ? WAVES : ((FEAT >= 2 && RTC_
     atomicAdd(&stats->analytic_tests, (unsigned long long)C.analytic_tests);
     atomicAdd(&stats->knodes, (unsigned long long)C.knodes);
     atomicAdd(&stats->kplanes, (unsigned long long)C.kplanes);
+    atomicAdd(&stats->light_cells, (unsigned long long)C.light_cells);
   }
 }
 
@@ -1438,7 +1537,12 @@ __device__ __forceinline__ void wf_trace_ray(const DScene& S, const DCamera& cam
   n_rays++;
   Trav T;
   reset_closest(T, MODE_CLOSEST);
-  traverse<FEAT, KOPS, MODE_CLOSEST, LDSC>(S, ray, T, C, stack, stride, L);
+  DIAG_LOOP(17);
+  {
+    DIAG_SPAN_BEGIN();
+    traverse<FEAT, KOPS, MODE_CLOSEST, LDSC>(S, ray, T, C, stack, stride, L);
+    DIAG_SPAN_END(0);
+  }
   const bool did_hit = T.best_prim != 0x7fffffff;
   if (level == 0 && hit_t) {
     hit_t[q] = did_hit ? T.best_t : 0.0;
@@ -1459,7 +1563,12 @@ __device__ __forceinline__ void wf_trace_ray(const DScene& S, const DCamera& cam
     K.mode = MODE_CONTAINERS;
     K.tlo = -DINF; K.thi = T.best_t;
     K.c1_prim = -1; K.c2_prim = -1; K.c1_t = 0.0; K.c2_t = 0.0;
-    traverse<FEAT, KOPS, MODE_CONTAINERS, LDSC>(S, ray, K, C, stack, stride, L);
+    DIAG_LOOP(19);
+    {
+      DIAG_SPAN_BEGIN();
+      traverse<FEAT, KOPS, MODE_CONTAINERS, LDSC>(S, ray, K, C, stack, stride, L);
+      DIAG_SPAN_END(1);
+    }
     if (K.c1_prim >= 0) n1 = S.mat[8 * S.prims[K.c1_prim].mat + 6];
     if (K.c2_prim >= 0) n2 = S.mat[8 * S.prims[K.c2_prim].mat + 6];
     W.h_n12[i] = n1; W.h_n12[cap + i] = n2;
@@ -1488,13 +1597,19 @@ __device__ __forceinline__ void wf_shadow_rec(const DScene& S, const DCamera& ca
     Trav Sh;
     reset_closest(Sh, S.all_cast_shadow ? MODE_SHADOW_ANY : MODE_SHADOW_CLOSEST);
     if (S.all_cast_shadow) { Sh.thi = distance; Sh.unordered = 1; }
+    Sh.light = l; Sh.c1_t = distance;
+    DIAG_LOOP(18);
+    DIAG_SPAN_BEGIN();
     if (S.all_cast_shadow) traverse<FEAT, KOPS, MODE_SHADOW_ANY, LDSC>(S, sray, Sh, C, stack, stride, L);  // mode: a compile-time constant in each
     else traverse<FEAT, KOPS, MODE_SHADOW_CLOSEST, LDSC>(S, sray, Sh, C, stack, stride, L);
+    DIAG_SPAN_END(3);
     bool shadowed;
     if (S.all_cast_shadow) shadowed = Sh.shadowed != 0;
     else shadowed = (Sh.best_prim != 0x7fffffff) && (S.prims[Sh.best_prim].flags & 1u) && (Sh.best_t < distance);
     if (shadowed) shadow_mask |= 1ull << l;
   }
+  DIAG_LOOP(20);
+  DIAG_SPAN_BEGIN();
   const double nx = r[3 * cap + s], ny = r[4 * cap + s], nz = r[5 * cap + s];
   const double cr = r[6 * cap + s], cg = r[7 * cap + s], cbl = r[8 * cap + s];
   // the eye vector (= -direction, src/intersection.rs:56) and the path weight of the ray come from where the ray itself came
@@ -1513,12 +1628,15 @@ __device__ __forceinline__ void wf_shadow_rec(const DScene& S, const DCamera& ca
   const double* M = S.mat + 8 * W.sr_mat[s];
   const double ambient = M[0], diffuse = M[1], specular = M[2], shininess = M[3];
   double sr = 0.0, sg = 0.0, sb = 0.0;
-  for (int l = 0; l < S.n_lights; l++) {
-    const double* LG = S.lights + 6 * l;
+  for (int l = 0; l < S.n_lights * ((RTC_PROBE & 8) ? 2 : 1); l++) {
+    if ((RTC_PROBE & 8) && l == S.n_lights) { sr = sg = sb = 0.0; }
+    const int li = (RTC_PROBE & 8) ? l % S.n_lights : l;
+    const double* LG = S.lights + 6 * li;
     double vx = LG[3] - px, vy = LG[4] - py, vz = LG[5] - pz;
+    if (RTC_PROBE & 8) RTC_LAUNDER(vx);
     double distance = sqrt(vx * vx + vy * vy + vz * vz);
     const double ldx = vx / distance, ldy = vy / distance, ldz = vz / distance;  // the shadow ray's direction again
-    const bool shadowed = (shadow_mask >> l) & 1ull;
+    const bool shadowed = (shadow_mask >> li) & 1ull;
     double er = cr * LG[0], eg = cg * LG[1], eb = cbl * LG[2];  // effective_color
     double lr = er * ambient, lg = eg * ambient, lb = eb * ambient;
     // light vector: (light.origin - point).normalize() — same numbers as the shadow ray direction
@@ -1539,6 +1657,7 @@ __device__ __forceinline__ void wf_shadow_rec(const DScene& S, const DCamera& ca
     sr += (lr + dr) + pr; sg += (lg + dg) + pg; sb += (lb + db) + pb;
   }
   cb[node] = weight * sr; cb[cap + node] = weight * sg; cb[2 * cap + node] = weight * sb;
+  DIAG_SPAN_END(5);
 }
 
 // Traversal kernel of the wavefront path: the closest-hit pass of level `tl` and the shadow + lighting pass of level `sl`
@@ -1566,8 +1685,12 @@ __global__ void __launch_bounds__(LDSC ? RTC_LDS_BLOCK : RTC_BLOCK, FEAT <= 1 ? 
     stride = (int)blockDim.x;
   }
 #endif
-  Counters C = {0, 0, 0, 0, 0, 0, 0};
+  Counters C = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned n_rays = 0, n_container = 0, n_shadow = 0;
+#ifdef RTC_DIAG
+  if (threadIdx.x < 64) s_diag[threadIdx.x] = 0ull;
+  __syncthreads();
+#endif
   const WorkMap wm = make_workmap(pm, cam);
   const unsigned nt = tl >= 0 ? wf_count(W, tl, n0) : 0u;
   unsigned ns = sl >= 0 ? W.counts[RTC_WF_SHADE_COUNT + sl] : 0u;
@@ -1587,17 +1710,29 @@ __global__ void __launch_bounds__(LDSC ? RTC_LDS_BLOCK : RTC_BLOCK, FEAT <= 1 ? 
       const unsigned base = (unsigned)chunk * RTC_WF_CHUNK;
       for (unsigned o = 0; o < RTC_WF_CHUNK; o += RTC_WF_LANES) {
         const unsigned i = base + o + (unsigned)lane;
-        if (i < nt) wf_trace_ray<FEAT, KOPS, LDSC>(S, cam, pm, W, wm, tl, i, hit_t, hit_prim, hit_k, stack, stride, C, n_rays, n_container, fuel_left, L);
+        if (i < nt) {
+          DIAG_SPAN_BEGIN();
+          wf_trace_ray<FEAT, KOPS, LDSC>(S, cam, pm, W, wm, tl, i, hit_t, hit_prim, hit_k, stack, stride, C, n_rays, n_container, fuel_left, L);
+          DIAG_SPAN_END(7);
+        }
       }
     } else {
       const unsigned base = (unsigned)(chunk - ct) * RTC_WF_CHUNK;
       for (unsigned o = 0; o < RTC_WF_CHUNK; o += RTC_WF_LANES) {
         const unsigned s = base + o + (unsigned)lane;
-        if (s < ns) wf_shadow_rec<FEAT, KOPS, LDSC>(S, cam, pm, W, wm, sl, s, stack, stride, C, n_shadow, L);
+        if (s < ns) {
+          DIAG_SPAN_BEGIN();
+          wf_shadow_rec<FEAT, KOPS, LDSC>(S, cam, pm, W, wm, sl, s, stack, stride, C, n_shadow, L);
+          DIAG_SPAN_END(7);
+        }
       }
     }
   }
   if (C.nan_ts) atomicAdd(&stats->nan_ts, (unsigned long long)C.nan_ts);
+#ifdef RTC_DIAG
+  __syncthreads();
+  if (threadIdx.x < 64 && s_diag[threadIdx.x]) atomicAdd(&stats->diag[threadIdx.x], s_diag[threadIdx.x]);
+#endif
   if (COUNT) {
     if (tl == 0) atomicAdd(&stats->rays_primary, (unsigned long long)n_rays);
     atomicAdd(&stats->rays_container, (unsigned long long)n_container);
@@ -1608,5 +1743,6 @@ __global__ void __launch_bounds__(LDSC ? RTC_LDS_BLOCK : RTC_BLOCK, FEAT <= 1 ? 
     atomicAdd(&stats->analytic_tests, (unsigned long long)C.analytic_tests);
     atomicAdd(&stats->knodes, (unsigned long long)C.knodes);
     atomicAdd(&stats->kplanes, (unsigned long long)C.kplanes);
+    atomicAdd(&stats->light_cells, (unsigned long long)C.light_cells);
   }
 }

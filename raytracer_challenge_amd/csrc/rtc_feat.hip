@@ -63,8 +63,11 @@ void RTC_CAT(rtc_launch_wf_ts_lds_v, RTC_VARIANT)(bool count, unsigned grid, uns
 #if RTC_VARIANT <= 1
   static bool raised = false;
   if (!raised) {  // more than 64 KB of dynamic LDS has to be asked for
-    (void)hipFuncSetAttribute((const void*)wf_ts<true, RTC_V_FEAT, RTC_V_KOPS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)wf_ts<false, RTC_V_FEAT, RTC_V_KOPS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // (static LDS of the kernel — the RTC_DIAG build has some — comes out of the same 160 KB)
+    hipFuncAttributes fa;
+    int st = hipFuncGetAttributes(&fa, (const void*)wf_ts<false, RTC_V_FEAT, RTC_V_KOPS, true>) == hipSuccess ? (int)fa.sharedSizeBytes : 0;
+    (void)hipFuncSetAttribute((const void*)wf_ts<true, RTC_V_FEAT, RTC_V_KOPS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - st);
+    (void)hipFuncSetAttribute((const void*)wf_ts<false, RTC_V_FEAT, RTC_V_KOPS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - st);
     raised = true;
   }
   if (count) hipLaunchKernelGGL((wf_ts<true, RTC_V_FEAT, RTC_V_KOPS, true>), dim3(grid), dim3(RTC_LDS_BLOCK), lds_bytes, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);

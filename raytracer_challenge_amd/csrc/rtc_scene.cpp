@@ -271,7 +271,7 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
     stats->rays_primary = h.rays_primary; stats->rays_shadow = h.rays_shadow; stats->rays_reflect = h.rays_reflect; stats->rays_refract = h.rays_refract;
     stats->rays_container = h.rays_container; stats->accel_nodes = h.accel_nodes; stats->group_tests = h.group_tests; stats->tri_tests = h.tri_tests;
     stats->analytic_tests = h.analytic_tests; stats->nan_ts = h.nan_ts;
-    stats->accel_nodes_kernarg = h.knodes; stats->analytic_tests_kernarg = h.kplanes;
+    stats->accel_nodes_kernarg = h.knodes; stats->analytic_tests_kernarg = h.kplanes; stats->light_grid_cells = h.light_cells;
     stats->kernel_ms = ms;
     stats->n_launches = wavefront ? 2u * (uint32_t)fuel + 4u : 1u;
   }
@@ -346,6 +346,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     d.has_csg = hv.has_csg;
     d.has_groups = hv.has_groups;
     d.has_recs = hv.has_recs;
+    d.light_grid_first = hv.light_grid_first;
     d.csg_max_hits = hv.csg_max_hits;
     d.csg_slab = nullptr;
     d.n_kops = hv.n_kops; d.n_kplanes = hv.n_kplanes;

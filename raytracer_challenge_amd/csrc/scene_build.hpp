@@ -190,6 +190,99 @@ struct ProgramBuilder {
     return (int32_t)qgrids.size() - 1;
   }
 
+  // Light grids.  Every shadow ray towards light l runs along a line through the light's position, so which
+  // primitives its segment can touch depends on its DIRECTION only: primitive B is a candidate for direction d iff some point x
+  // of B's bounds has (l - x) / |l - x| = d.  Per light a cube map of n x n cells per face (the quirk grid's cell function) lists,
+  // per cell, the primitives of the analytic BVH whose bounds have such a point for some direction of the cell, as the leaf
+  // references the BVH itself would hand the walk: a shadow ray looks its cell up, puts the list on its traversal stack and runs
+  // the walk's leaf loop — no frame, no node steps.  The lists are supersets of what the walk would reach (the walk also culls by
+  // distance), the exact tests are the same, so the results are.  Returns 1 + index of light 0's grid in qgrids, 0 = not built.
+  int32_t build_light_grids(const std::vector<bvh::Item>& boxes, const std::vector<int32_t>& ids) {
+    const char* e = std::getenv("RTC_LIGHT_GRID");
+    if ((e && e[0] == '0') || D.n_lights == 0 || boxes.size() < 16) return 0;
+    const char* en = std::getenv("RTC_LIGHT_GRID_N");
+    // cells per face edge: 256 (config 2: 12 % fewer candidates than 128, -4 % frame time; 64: +10 %) while the cell arrays of all
+    // lights stay small beside the caches (1.5 MB per light at 256)
+    const int n = en ? std::min(512, std::max(2, std::atoi(en))) : (D.n_lights <= 4 ? 256 : (D.n_lights <= 16 ? 128 : 64));
+    // the first candidate is walked at once, the others wait on the traversal stack, whose depth the BVH decided: a cell with more
+    // candidates than that holds the one reference RTC_LIGHT_CELL_WALK instead — its rays walk the BVH like any other ray
+    const int max_list = std::max(8, max_stack + 1);
+    const size_t g0 = qgrids.size(), c0 = qcell.size(), i0 = items.size();
+    for (uint32_t l = 0; l < D.n_lights; l++) {
+      const double* o = D.lights[l].origin;
+      std::vector<uint32_t> count((size_t)6 * n * n + 1, 0u);
+      struct Rect { int32_t face, u0, u1, v0, v1, ref; float dmin; };
+      std::vector<Rect> rects;
+      auto cell = [&](double u) {
+        int i = (int)((u + 1.0) * 0.5 * (double)n);
+        return i < 0 ? 0 : (i >= n ? n - 1 : i);
+      };
+      bool ok = std::isfinite(o[0]) && std::isfinite(o[1]) && std::isfinite(o[2]);
+      for (size_t k = 0; k < boxes.size() && ok; k++) {
+        double a[3], b[3];  // w = l - x over the box
+        for (int c = 0; c < 3; c++) { a[c] = o[c] - boxes[k].hi[c]; b[c] = o[c] - boxes[k].lo[c]; if (!(a[c] <= b[c])) ok = false; }
+        const int32_t ref = ~(int32_t)((uint32_t)ids[k] << 3);
+        // no point of the box is nearer to the light than this (rounded down): a shadow ray shorter than that starts between the
+        // light and the box, which then lies behind its origin
+        double d2 = 0.0;
+        for (int c = 0; c < 3; c++) { const double g = a[c] > 0.0 ? a[c] : (b[c] < 0.0 ? -b[c] : 0.0); d2 += g * g; }
+        float dmin = (float)(std::sqrt(d2) * (1.0 - 1e-6));
+        dmin = dmin > 0.0f ? std::nextafterf(dmin, 0.0f) : 0.0f;
+        for (int face = 0; face < 6 && ok; face++) {
+          const int ax = face >> 1;
+          const double m_lo = (face & 1) ? -b[ax] : a[ax], m_hi = (face & 1) ? -a[ax] : b[ax];  // range of the dominant |component|
+          if (!(m_hi > 0.0)) continue;
+          const int iu = ax == 0 ? 1 : 0, iv = ax == 2 ? 1 : 2;  // the cell function's (u, v): the other two axes in x, y, z order
+          double lo2[2], hi2[2];
+          bool none = false;
+          for (int c = 0; c < 2; c++) {
+            const int q = c == 0 ? iu : iv;
+            double hi = b[q] > 0.0 ? (m_lo > 0.0 ? b[q] / m_lo : rth::kInf) : b[q] / m_hi;
+            double lo = a[q] < 0.0 ? (m_lo > 0.0 ? a[q] / m_lo : -rth::kInf) : a[q] / m_hi;
+            const double tol = 1e-9;  // device and host may disagree on the cell of a direction on an edge
+            lo -= tol * (1.0 + std::fabs(lo)); hi += tol * (1.0 + std::fabs(hi));
+            if (lo > 1.0 || hi < -1.0) none = true;
+            lo2[c] = std::fmax(lo, -1.0); hi2[c] = std::fmin(hi, 1.0);
+          }
+          if (none) continue;
+          Rect r{face, cell(lo2[0]), cell(hi2[0]), cell(lo2[1]), cell(hi2[1]), ref, dmin};
+          rects.push_back(r);
+          for (int v = r.v0; v <= r.v1; v++)
+            for (int u = r.u0; u <= r.u1; u++) count[((size_t)face * n + v) * n + u]++;
+        }
+      }
+      if (!ok) { qgrids.resize(g0); qcell.resize(c0); items.resize(i0); return 0; }
+      uint32_t longest = 0, walks = 0;
+      unsigned long long total = 0;
+      for (uint32_t& c : count) {
+        longest = std::max(longest, c);
+        if ((int)c > max_list) { c = 0x80000001u; walks++; } else total += c;
+      }
+      if (std::getenv("RTC_TIMING"))
+        std::fprintf(stderr, "[rtc-timing]   light grid %u: n %d, %llu items, longest list %u, %u cells left to the BVH walk (more than %d candidates)\n", l, n, total, longest, walks, max_list);
+      // a cell's items: pairs {leaf reference, dmin as f32 bits}, nearest to the light first (8-byte aligned for one load each)
+      if (items.size() & 1u) items.push_back(0);
+      DQuirkGrid g{n, (int32_t)qcell.size(), 0, 0};
+      std::vector<uint32_t> at(count.size());
+      uint32_t run = (uint32_t)items.size();
+      for (size_t c = 0; c < count.size(); c++) { at[c] = run; qcell.push_back(run); run += 2u * (count[c] & 0x7fffffffu); }
+      items.resize(run);
+      for (size_t c = 0; c < count.size(); c++) if (count[c] & 0x80000000u) { items[at[c]] = RTC_LIGHT_CELL_WALK; items[at[c] + 1] = 0; at[c] = 0xffffffffu; }
+      std::sort(rects.begin(), rects.end(), [](const Rect& x, const Rect& y) { return x.dmin < y.dmin || (x.dmin == y.dmin && x.ref > y.ref); });
+      for (const Rect& r : rects)
+        for (int v = r.v0; v <= r.v1; v++)
+          for (int u = r.u0; u <= r.u1; u++) {
+            uint32_t& w = at[((size_t)r.face * n + v) * n + u];
+            if (w == 0xffffffffu) continue;
+            items[w] = r.ref;
+            std::memcpy(&items[w + 1], &r.dmin, 4);
+            w += 2;
+          }
+      qgrids.push_back(g);
+    }
+    return (int32_t)g0 + 1;
+  }
+
   // Leaf sizes: an analytic primitive test (own matrix, geometry switch) is ~3x an inner node and runs at poor lane
   // utilisation, so analytic leaves hold one primitive; packed triangles are cheap and uniform, so mesh leaves hold four.
   static int leaf_size(bool mesh) {
@@ -292,6 +385,8 @@ struct ProgramBuilder {
   }
 
   int csg_max_hits = 0;
+  size_t n_plain_items = (size_t)-1;  // items[0, n_plain_items) are primitive indices (quirk lists, quirk-grid cells); the rest light-grid pairs
+  std::vector<int32_t>& items_member() { return this->items; }
   bvh::DeviceBuildFn device_build = nullptr;  // set by rtc_scene_create when the accelerator is to be built on the device
   size_t device_build_min = 4096;
   int built_on_device = 0;
@@ -379,6 +474,7 @@ struct ProgramBuilder {
           for (int32_t& c : bvh_nodes[ni].c) c = direct(c);
         for (int32_t pi : ids) bvh_prims.push_back(pi);
         root = direct(root);
+        const size_t bvh_op = ops.size();
         ops.push_back({OP_BVH, root, 0, fi, -1, {0, 0, 0}});
         int32_t q0 = (int32_t)quirk_prim.size();
         for (int32_t pi : ids)
@@ -386,6 +482,9 @@ struct ProgramBuilder {
         int32_t qn = (int32_t)quirk_prim.size() - q0;
         if (qn >= kMinQuirkGrid) ops.push_back({OP_QGRID, build_quirk_grid(q0, qn), 0, 0, -1, {0, 0, 0}});
         else if (qn > 0) ops.push_back({OP_QUIRK, q0, qn, 0, -1, {0, 0, 0}});
+        // light grids last: their {reference, distance} pairs form the tail of the item array, after every plain primitive index
+        n_plain_items = items_member().size();
+        if (root >= 0) ops[bvh_op].b = build_light_grids(items, ids);  // (a root that is itself a leaf needs no help)
       }
     }
     // 3. CSG groups: linear sub-programs, gated by their enclosing aggregation groups
@@ -453,6 +552,7 @@ struct HostArrays {
   std::vector<DBvhNode4> bvh;
   std::vector<double> mtri;
   std::vector<int32_t> mtri_prim, items;  // items: BVH leaf items + quirk lists + grid cells, absolute indices
+  size_t n_plain_items = (size_t)-1;       // items from here on are light-grid {leaf reference, distance} pairs, not primitive indices
   std::vector<DQuirkGrid> qgrids;
   std::vector<uint32_t> qcell;
   std::vector<double> bvh_frame;
@@ -516,10 +616,12 @@ struct HostArrays {
     for (const DOp& o : ops) if (o.g >= 0) d.has_groups = 1;
     // a mesh triangle inherits its OP_MESH gate; only primitives reached one by one need their own
     for (const DOp& o : ops) if ((o.op == OP_PRIM) && prims[o.a].gcond >= 0) d.has_groups = 2;
-    for (int32_t pi : items) if (prims[pi].gcond >= 0) d.has_groups = 2;
+    for (size_t i = 0; i < std::min(items.size(), n_plain_items); i++) if (prims[items[i]].gcond >= 0) d.has_groups = 2;  // (light-grid items name bvh_prims)
     for (int32_t pi : bvh_prims) if (prims[pi].gcond >= 0) d.has_groups = 2;
     for (const DOp& o : ops) { if (o.op == OP_MESH) d.has_mesh = 1; if (o.op == OP_CSG) d.has_csg = 1; }
     fill_kernarg_program(d);
+    d.light_grid_first = 0;
+    for (const DOp& o : ops) if (o.op == OP_BVH && o.b > 0) d.light_grid_first = o.b;
     d.has_recs = 0;
     for (size_t i = 0; i < ops.size(); i++) {
       const DOp& o = ops[i];
@@ -610,6 +712,7 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
   H->mtri = std::move(pb.mtri);
   H->mtri_prim = std::move(pb.mtri_prim);
   H->items = std::move(pb.items);
+  H->n_plain_items = pb.n_plain_items;
   H->bvh_prims = std::move(pb.bvh_prims);
   H->qgrids = std::move(pb.qgrids);
   H->qcell = std::move(pb.qcell);

@@ -21,10 +21,10 @@ class RtcStatsC(C.Structure):
                  "accel_nodes", "group_tests", "tri_tests", "analytic_tests", "nan_ts")
     _fields_ = [(n, C.c_uint64) for n in _COUNTERS] + \
                [("kernel_ms", C.c_double), ("n_launches", C.c_uint32), ("_pad", C.c_uint32),
-                ("accel_nodes_kernarg", C.c_uint64), ("analytic_tests_kernarg", C.c_uint64)]
+                ("accel_nodes_kernarg", C.c_uint64), ("analytic_tests_kernarg", C.c_uint64), ("light_grid_cells", C.c_uint64)]
 
     def as_dict(self):
-        d = {n: int(getattr(self, n)) for n in self._COUNTERS + ("accel_nodes_kernarg", "analytic_tests_kernarg")}
+        d = {n: int(getattr(self, n)) for n in self._COUNTERS + ("accel_nodes_kernarg", "analytic_tests_kernarg", "light_grid_cells")}
         d["kernel_ms"] = float(self.kernel_ms)
         d["n_launches"] = int(self.n_launches)
         d["unique_rays"] = d["rays_primary"] + d["rays_shadow"] + d["rays_reflect"] + d["rays_refract"]
@@ -41,6 +41,7 @@ UNIT_BYTES = {
     "triangle": 72,   # p1, e1, e2 (f64)
     "analytic": 128,  # one intersection record (DPrimI: rows 0-2 of transform_inv + limits + tags)
     "pixel": 24,      # framebuffer write (3 x f64)
+    "light_cell": 16, # one light-grid lookup of a shadow ray: two 4-B cell offsets + on average two 4-B candidate references
 }
 KERNARG_BYTES = {"node": 128, "plane": 48}
 
@@ -64,6 +65,7 @@ def algorithmic_bytes(st: dict, path: str, n_prims: int = 0, lds_tables: bool = 
         "triangle": 0 if lds else tri_b,
         "analytic": 0 if lds else ana_b,
         "pixel": UNIT_BYTES["pixel"] * st["pixels"],
+        "light_cell": UNIT_BYTES["light_cell"] * st.get("light_grid_cells", 0),
     }
     counted = sum(by_unit.values())
     ideal = 96 + 64 * math.ceil(math.log2(max(2, n_prims))) + 72 * 4

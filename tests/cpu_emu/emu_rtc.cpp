@@ -69,7 +69,7 @@ static int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double*
     stats->rays_primary = st.rays_primary; stats->rays_shadow = st.rays_shadow; stats->rays_reflect = st.rays_reflect; stats->rays_refract = st.rays_refract;
     stats->rays_container = st.rays_container; stats->accel_nodes = st.accel_nodes; stats->group_tests = st.group_tests; stats->tri_tests = st.tri_tests;
     stats->analytic_tests = st.analytic_tests; stats->nan_ts = st.nan_ts;
-    stats->accel_nodes_kernarg = st.knodes; stats->analytic_tests_kernarg = st.kplanes;
+    stats->accel_nodes_kernarg = st.knodes; stats->analytic_tests_kernarg = st.kplanes; stats->light_grid_cells = st.light_cells;
     stats->n_launches = n_launches;
   }
   if (st.guard) return efail(RTC_ERR_DEVICE, "traversal guard tripped (mask " + std::to_string(st.guard) + ")");

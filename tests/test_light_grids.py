@@ -1,0 +1,76 @@
+"""Light grids (scene_build.hpp build_light_grids): a shadow ray takes its candidates from its light's direction grid
+instead of walking the analytic BVH.  Results-neutral by construction, so a scene rendered with the grids (default) and without
+(RTC_LIGHT_GRID=0) must give the same pixels and hit records bit for bit, on both device paths — and the counters must show that
+the grids really stood in for walks."""
+import numpy as np
+import pytest
+
+from parity import assert_parity
+from raytracer_challenge_amd import scenes
+from raytracer_challenge_amd.device import DeviceRenderer
+
+
+def both_ways(be, world, cam, fuel, monkeypatch, idx=None, kernels=("1", "4")):
+    out = {}
+    for k in kernels:
+        monkeypatch.setenv("RTC_KERNEL", k)
+        for flag in ("0", "1"):
+            monkeypatch.setenv("RTC_LIGHT_GRID", flag)
+            out[k, flag] = be.render(be.build_world(world), cam, fuel, idx)
+    ref = out[kernels[0], "0"]
+    for key, (rgb, hits) in out.items():
+        assert np.array_equal(hits, ref[1]), key
+        assert np.array_equal(rgb, ref[0]), key
+    monkeypatch.delenv("RTC_LIGHT_GRID")
+    monkeypatch.delenv("RTC_KERNEL")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from emu_lib import emu as _emu
+    return _emu()
+
+
+@pytest.mark.parametrize("cones,grouped", [(False, False), (True, True)])
+def test_light_grids_are_results_neutral_in_the_emulator(emu, orc, monkeypatch, cones, grouped):
+    cam, world = scenes.synthetic_analytic(n_primitives=96, seed=7, cones=cones, grouped=grouped, hsize=96, vsize=54)
+    both_ways(emu, world, cam, 3, monkeypatch)
+    assert_parity(emu, orc, world, cam, 3, label="synthetic analytic, light grids on")
+
+
+def test_light_grid_counters_in_the_emulator(emu, monkeypatch):
+    """With grids: one cell lookup per shadow ray (minus the rays of over-full cells) and far fewer accelerator nodes."""
+    import torch
+    cam, world = scenes.synthetic_analytic(n_primitives=96, seed=7, hsize=96, vsize=54)
+    st = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RTC_LIGHT_GRID", flag)
+        dr = DeviceRenderer(emu, emu.build_world(world), cam, 0, _cpu_standin=True)
+        out = torch.empty(cam.vsize * cam.hsize * 3, dtype=torch.float64)
+        st[flag] = dr.render_rows(3, 0, 1, cam.vsize, out, count=True, sync=True)
+        st[flag]["img"] = out.clone()
+    assert torch.equal(st["0"]["img"], st["1"]["img"])
+    assert st["0"]["light_grid_cells"] == 0
+    assert 0.9 * st["1"]["rays_shadow"] <= st["1"]["light_grid_cells"] <= st["1"]["rays_shadow"]
+    assert st["1"]["accel_nodes"] < 0.6 * st["0"]["accel_nodes"]
+    for k in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract"):
+        assert st["0"][k] == st["1"][k], k
+
+
+def test_light_inside_a_primitive_and_degenerate_shadow_rays(emu, orc, monkeypatch):
+    """A light inside primitives' bounds (those are candidates of every cell) and a light ON a surface (zero-length shadow rays: the
+    direction is NaN, the cell function declines, the ray walks the BVH)."""
+    from raytracer_challenge_amd.scene import Color, PointLight, Vector
+    cam, world = scenes.synthetic_analytic(n_primitives=64, seed=3, hsize=64, vsize=36)
+    world.lights.append(PointLight(Color.new(0.5, 0.5, 0.5), Vector.point(0.0, 1.0, 0.0)))
+    world.lights.append(PointLight(Color.new(0.2, 0.2, 0.2), Vector.point(0.3, 0.0, 0.2)))   # on the floor plane
+    both_ways(emu, world, cam, 2, monkeypatch)
+    assert_parity(emu, orc, world, cam, 2, label="lights inside bounds / on a surface")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cones,grouped", [(False, False), (True, True)])
+def test_hip_light_grids_are_results_neutral(hip, orc, monkeypatch, cones, grouped):
+    cam, world = scenes.synthetic_analytic(n_primitives=512, seed=12345, cones=cones, grouped=grouped, hsize=480, vsize=270)
+    both_ways(hip, world, cam, 5, monkeypatch)
+    assert_parity(hip, orc, world, cam, 5, np.arange(0, 480 * 270, 7, dtype=np.uint64), label="config-2 scene at 480x270, light grids on")
