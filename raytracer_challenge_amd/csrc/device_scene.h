@@ -158,6 +158,7 @@ struct DScene {
   int32_t has_csg;           // 1: the program contains an OP_CSG
   int32_t has_groups;        // 0: no gates; 1: only OP_MESH / OP_CSG ops are gated; 2: individual primitives are gated
   int32_t csg_max_hits;      // most intersections one top-level CSG subtree can produce
+  int32_t light_grid_n, light_grid_cell_off;  // the light grids' common n and light 0's cell_off (light l: + l * (6 n^2 + 1))
   int32_t light_grid_first;  // 0 or 1 + index in qgrids of light 0's light grid (= the b of the program's OP_BVH)
   int32_t has_recs;          // 1: some op reads intersection records (pisect): analytic BVH, quirk scans, primitives outside the kernel arguments
   // Kernel-argument copy of a short traversal program (kernargs are read with scalar loads: the op fetch and the plane

@@ -490,7 +490,8 @@ __device__ __forceinline__ LightCell light_grid_fetch(const DScene& S, const Ray
   c.i0.ref = RTC_WALK_END; c.i0.dmin = 0.0f; c.i1 = c.i0;
   if (MODE == MODE_CLOSEST || MODE == MODE_CONTAINERS) return c;
   if (S.light_grid_first <= 0 || T.light < 0) return c;
-  if (!dir_grid_cell(S, S.qgrids[S.light_grid_first - 1 + T.light], r, c.b, c.e)) return c;
+  const DQuirkGrid G = {S.light_grid_n, S.light_grid_cell_off + T.light * (6 * S.light_grid_n * S.light_grid_n + 1), 0, 0};  // (no fetch of the grid's record)
+  if (!dir_grid_cell(S, G, r, c.b, c.e)) return c;
   c.state = 1;
   if (c.b < c.e) c.i0 = *(const DLightItem*)(S.qitem + c.b);  // (8-byte aligned by the builder)
   if (c.b + 2 < c.e) c.i1 = *(const DLightItem*)(S.qitem + c.b + 2);

@@ -622,6 +622,8 @@ struct HostArrays {
     fill_kernarg_program(d);
     d.light_grid_first = 0;
     for (const DOp& o : ops) if (o.op == OP_BVH && o.b > 0) d.light_grid_first = o.b;
+    d.light_grid_n = 0; d.light_grid_cell_off = 0;
+    if (d.light_grid_first > 0) { d.light_grid_n = qgrids[(size_t)d.light_grid_first - 1].n; d.light_grid_cell_off = qgrids[(size_t)d.light_grid_first - 1].cell_off; }
     d.has_recs = 0;
     for (size_t i = 0; i < ops.size(); i++) {
       const DOp& o = ops[i];
