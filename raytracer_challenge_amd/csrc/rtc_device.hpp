@@ -68,7 +68,7 @@
 #endif
 #define DINF (__builtin_inf())
 #ifndef RTC_PROBE
-#define RTC_PROBE 0  // cost probes (scripts/build_variant.sh ... -DRTC_PROBE=<bits>): a section runs twice, pixels unchanged. 1 planes, 2 quirk grid, 4 node steps, 8 Phong, 16 analytic leaf tests
+#define RTC_PROBE 0  // cost probes (scripts/build_variant.sh ... -DRTC_PROBE=<bits>): a section runs twice, pixels unchanged. 1 planes, 2 quirk grid, 4 node steps, 8 Phong, 16 analytic leaf tests, 32 container passes (wavefront path)
 #endif
 // RTC_LAUNDER(x): the compiler may not assume it knows x's value any more.  Used on a work item's index right after a traversal:
 // without it every output address derived from the index before the traversal (hipcc computes them all up front) stays live
@@ -545,7 +545,24 @@ __device__ __forceinline__ bool light_grid_candidates(const DScene& S, const Lig
 // relative to c takes every box (id = 0 makes every slab interval [0, 0]).
 struct Frame32 {
   float olx, oly, olz, ohx, ohy, ohz, ix, iy, iz;  // ol / oh: (origin + eps) * i and (origin - eps) * i, see make_frame
+  float px, py, pz, pm;  // container passes of the wavefront path: the hit point in the frame and its margin (make_frame_point)
 };
+// Container pass: a sphere or a cube reports 0 or 2 intersections, both inside its bounds, so it has an ODD number of
+// them before the hit only if the hit point X = o + t_hit d lies between the two — inside its (convex, padded) bounds.  A leaf of such a
+// primitive (bit 0 of its reference, set by the builder) is therefore taken only if X is inside the leaf's box, widened by pm; every
+// other leaf (cylinders and cones can report 1 or 3: open ends, rims) and every inner node is taken when the LINE meets its box, as ever.
+__device__ __forceinline__ void make_frame_point(const double* __restrict__ fr, const Ray& o, double t_hit, Frame32& f) {
+  const float x = (float)((o.ox + t_hit * o.dx) - fr[0]), y = (float)((o.oy + t_hit * o.dy) - fr[1]), z = (float)((o.oz + t_hit * o.dz) - fr[2]);
+  const float ox = (float)(o.ox - fr[0]), oy = (float)(o.oy - fr[1]), oz = (float)(o.oz - fr[2]);
+  float m = fmaxf(fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z)), fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz))) + (float)fr[3];
+  f.px = x; f.py = y; f.pz = z;
+  f.pm = m * 9.5367431640625e-07f + 1e-30f;  // 2^-20 (|X| + |o| + R), the scale of make_frame's eps
+  if (!(m < 1e30f)) f.pm = __builtin_inff();  // no usable point: every box "contains" it (a NaN point fails every comparison below, so:)
+  if (!(x == x) || !(y == y) || !(z == z)) { f.px = 0.0f; f.py = 0.0f; f.pz = 0.0f; f.pm = __builtin_inff(); }
+}
+__device__ __forceinline__ bool point_in_box(float lx, float ly, float lz, float hx, float hy, float hz, const Frame32& f) {
+  return lx - f.pm <= f.px && f.px <= hx + f.pm && ly - f.pm <= f.py && f.py <= hy + f.pm && lz - f.pm <= f.pz && f.pz <= hz + f.pm;
+}
 __device__ __forceinline__ void make_frame(const double* __restrict__ fr, const Ray& o, Frame32& f) {
   float ox = (float)(o.ox - fr[0]), oy = (float)(o.oy - fr[1]), oz = (float)(o.oz - fr[2]);
   float m = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz)) + (float)fr[3];
@@ -584,6 +601,7 @@ __device__ __forceinline__ bool slab32c(float lx, float ly, float lz, float hx, 
 
 // One inner-node step of the walk: the node's four child boxes against the ray; hits ordered nearest first, the nearest
 // becomes `cur`, the others are stacked; no hit pops (or ends the walk: cur = END).
+template <bool PM = false>  // PM: container pass with a hit point in F (see make_frame_point)
 __device__ __forceinline__ void node_step(const float4 lox, const float4 loy, const float4 loz, const float4 hix, const float4 hiy, const float4 hiz, const int4 cc,
                                           const Frame32& F, float lo, float hi, int& cur, int& sp, int* __restrict__ stack, int stride, bool any_hit) {
   const float FINF = __builtin_inff();
@@ -592,6 +610,12 @@ __device__ __forceinline__ void node_step(const float4 lox, const float4 loy, co
   bool h1 = slab32c(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, F, lo, hi, t1);
   bool h2 = slab32c(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, F, lo, hi, t2);
   bool h3 = slab32c(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, F, lo, hi, t3);
+  if (PM) {
+    if (cc.x < 0 && ((~cc.x) & 1)) h0 = h0 && point_in_box(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, F);
+    if (cc.y < 0 && ((~cc.y) & 1)) h1 = h1 && point_in_box(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, F);
+    if (cc.z < 0 && ((~cc.z) & 1)) h2 = h2 && point_in_box(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, F);
+    if (cc.w < 0 && ((~cc.w) & 1)) h3 = h3 && point_in_box(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, F);
+  }
   const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
   if (nh == 0) {
     if (sp == 0) cur = RTC_WALK_END;
@@ -626,6 +650,7 @@ __device__ __forceinline__ void node_step(const float4 lox, const float4 loy, co
 
 // First step of a walk whose root node travels in the kernel arguments (DScene.kaux; scalar loads): every lane starts at the
 // root, so its boxes need no vector load.
+template <bool PM = false>
 __device__ __forceinline__ void walk_root_k(const DBvhNode4& R, const Frame32& F, const Trav& T, Counters& C, int& cur, int& sp, int* __restrict__ stack, int stride) {
   C.accel_nodes++;
   C.knodes++;
@@ -635,13 +660,13 @@ __device__ __forceinline__ void walk_root_k(const DBvhNode4& R, const Frame32& F
   const float4 loz = {R.loz[0], R.loz[1], R.loz[2], R.loz[3]}, hix = {R.hix[0], R.hix[1], R.hix[2], R.hix[3]};
   const float4 hiy = {R.hiy[0], R.hiy[1], R.hiy[2], R.hiy[3]}, hiz = {R.hiz[0], R.hiz[1], R.hiz[2], R.hiz[3]};
   const int4 cc = {R.c[0], R.c[1], R.c[2], R.c[3]};
-  node_step(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride, T.mode == MODE_SHADOW_ANY && T.unordered);
+  node_step<PM>(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride, T.mode == MODE_SHADOW_ANY && T.unordered);
 }
 
 // The walk itself, from (cur, sp): ONE inlined copy per traversal (the op loop sets the walk up per lane and all walks of a
 // program — mesh or analytic, kernel-argument root or not — run through this loop).  `mesh` is uniform across the wave (it comes
 // from the program op): leaves hold triangles of the packed arrays (object-space ray `o`) or name one analytic primitive.
-template <int FEAT, bool LDSC = false>
+template <int FEAT, bool LDSC = false, bool PM = false>
 __device__ __forceinline__ void walk_loop(const DScene& S, const bool mesh, int cur, int sp, const Frame32& F, const Ray& world, const Ray& o, Trav& T, Counters& C,
                                           int* __restrict__ stack, int stride, const LdsScene& L = LdsScene{}) {
   const int END = RTC_WALK_END;
@@ -670,11 +695,11 @@ __device__ __forceinline__ void walk_loop(const DScene& S, const bool mesh, int 
       }
       if (RTC_PROBE & 4) {  // cost probe: the node step twice (same pushes, same result)
         const int cur0 = cur, sp0 = sp;
-        node_step(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride, any_hit);
+        node_step<PM>(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride, any_hit);
         RTC_LAUNDER(lox.x);
         cur = cur0; sp = sp0;
       }
-      node_step(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride, any_hit);
+      node_step<PM>(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride, any_hit);
     }
     if (cur == END) return;
     {
@@ -847,15 +872,17 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
           const DKAux& A = S.kaux[op.pad[0]];
           if (mesh) o = to_object(A.xf, r);
           make_frame(A.frame, o, F);
+          if (MODE == MODE_CONTAINERS) make_frame_point(A.frame, o, T.thi, F);
 #ifndef RTC_NO_KROOT
-          walk_root_k(A.root, F, T, C, cur, sp, stack, stride);
+          walk_root_k<MODE == MODE_CONTAINERS>(A.root, F, T, C, cur, sp, stack, stride);
 #endif
         } else {
           if (mesh) o = to_object(S.xf_inv + 12 * op.b, r);
           make_frame(S.bvh_frame + 4 * op.c, o, F);
+          if (MODE == MODE_CONTAINERS) make_frame_point(S.bvh_frame + 4 * op.c, o, T.thi, F);
         }
       }
-      if (walk) walk_loop<FEAT, LDSC>(S, mesh, cur, sp, F, r, o, T, C, stack, stride, L);
+      if (walk) walk_loop<FEAT, LDSC, MODE == MODE_CONTAINERS>(S, mesh, cur, sp, F, r, o, T, C, stack, stride, L);
       if (T.mode == MODE_SHADOW_ANY && T.shadowed) return;
     }
     return;
@@ -896,11 +923,12 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
         } else {
           if (mesh) o = to_object(S.xf_inv + 12 * op.b, r);
           make_frame(S.bvh_frame + 4 * op.c, o, F);
+          if (MODE == MODE_CONTAINERS) make_frame_point(S.bvh_frame + 4 * op.c, o, T.thi, F);
         }
       }
       pc++;
     }
-    if (walk) walk_loop<FEAT, LDSC>(S, mesh, cur, sp, F, r, o, T, C, stack, stride, L);
+    if (walk) walk_loop<FEAT, LDSC, MODE == MODE_CONTAINERS>(S, mesh, cur, sp, F, r, o, T, C, stack, stride, L);
     if (T.mode == MODE_SHADOW_ANY && T.shadowed) return;
   }
 }
@@ -1567,7 +1595,12 @@ __device__ __forceinline__ void wf_trace_ray(const DScene& S, const DCamera& cam
     DIAG_LOOP(19);
     {
       DIAG_SPAN_BEGIN();
-      traverse<FEAT, KOPS, MODE_CONTAINERS, LDSC>(S, ray, K, C, stack, stride, L);
+#pragma unroll 1
+      for (int rep_ = 0; rep_ < ((RTC_PROBE & 32) ? 2 : 1); rep_++) {
+        Ray r2 = ray;
+        if (RTC_PROBE & 32) RTC_LAUNDER(r2.ox);
+        traverse<FEAT, KOPS, MODE_CONTAINERS, LDSC>(S, r2, K, C, stack, stride, L);
+      }
       DIAG_SPAN_END(1);
     }
     if (K.c1_prim >= 0) n1 = S.mat[8 * S.prims[K.c1_prim].mat + 6];

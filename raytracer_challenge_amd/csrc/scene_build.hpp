@@ -469,7 +469,14 @@ struct ProgramBuilder {
         size_t first_node = bvh_nodes.size();
         int32_t root = build_tree(items, order, base, false, &fi);
         // analytic leaves hold ONE primitive: the leaf ref carries the primitive index itself (no item indirection)
-        auto direct = [&](int32_t ref) { return ref >= 0 ? ref : ~(int32_t)(((uint32_t)ids[order[((uint32_t)~ref >> 3) - base]] << 3) | 0u); };
+        // bit 0 of the (otherwise unused) item-count field: the primitive is a sphere or a cube — 0 or 2 intersections, both inside
+        // its bounds — which lets a container pass skip it unless the hit point lies inside the leaf's box (rtc_device.hpp, make_frame_point)
+        auto direct = [&](int32_t ref) {
+          if (ref >= 0) return ref;
+          const int32_t pi = ids[order[((uint32_t)~ref >> 3) - base]];
+          const uint32_t two = (D.prims[pi].geometry == RTC_SPHERE || D.prims[pi].geometry == RTC_CUBE) ? 1u : 0u;
+          return ~(int32_t)(((uint32_t)pi << 3) | two);
+        };
         for (size_t ni = first_node; ni < bvh_nodes.size(); ni++)
           for (int32_t& c : bvh_nodes[ni].c) c = direct(c);
         for (int32_t pi : ids) bvh_prims.push_back(pi);
