@@ -46,8 +46,11 @@ static int rtc_variant(const DScene& S) {
 #endif
 template <bool COUNT>
 __global__ void __launch_bounds__(RTC_WF_SHADE_BLOCK, RTC_WF_SHADE_WAVES) wf_shade(DScene S, DCamera cam, DPixelMap pm, DWave W, int level, unsigned n0, int fuel0, DStats* __restrict__ stats) {
-  __shared__ unsigned s_rec2[2][16], s_child2[2][16];  // per wave: its count, then its base index in the queue (double-buffered
-                                                       // by iteration parity: no barrier needed before the next iteration writes)
+  // per wave and class: its count, then its base index in the queue (double-buffered by iteration parity: no barrier needed before
+  // the next iteration writes).  Classes keep like with like inside a block's span of the queues, so that most 64-item chunks of the
+  // next traversal launch hold one kind of ray: shade records on planes / on other primitives; reflected rays off planes (mirror
+  // images of their coherent parents) / off other primitives / refracted rays.
+  __shared__ unsigned s_rec2[2][2][16], s_child2[2][3][16];
   unsigned parity = 0;
   const WorkMap wm = make_workmap(pm, cam);
   const unsigned count = wf_count(W, level, n0);
@@ -67,7 +70,7 @@ __global__ void __launch_bounds__(RTC_WF_SHADE_BLOCK, RTC_WF_SHADE_WAVES) wf_sha
     const bool hit = prim >= 0;
     State st;
     double cr = 0.0, cg = 0.0, cbl = 0.0, weight = 1.0, n1 = 1.0, n2 = 1.0;
-    int mat = 0;
+    int mat = 0, geom = 0;
     double reflective = 0.0, transparency = 0.0;
     if (hit) {
       Ray ray;
@@ -80,6 +83,7 @@ __global__ void __launch_bounds__(RTC_WF_SHADE_BLOCK, RTC_WF_SHADE_WAVES) wf_sha
       }
       const DPrim P = S.prims[prim];
       mat = P.mat;
+      geom = P.geom;
       const double* M = S.mat + 8 * P.mat;
       reflective = M[4]; transparency = M[5];
       double hu, hv;
@@ -123,28 +127,32 @@ __global__ void __launch_bounds__(RTC_WF_SHADE_BLOCK, RTC_WF_SHADE_WAVES) wf_sha
     // queue space: shade records and child rays (a wave's reflected rays first, then its refracted ones); one pair of
     // atomics per block and iteration
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const unsigned long long m_rec = __ballot(hit ? 1 : 0), m_refl = __ballot(do_refl ? 1 : 0), m_refr = __ballot(do_refr ? 1 : 0);
-    unsigned* s_rec = s_rec2[parity];
-    unsigned* s_child = s_child2[parity];
+    const bool on_plane = hit && geom == 1;
+    const unsigned long long m_rec0 = __ballot(hit && on_plane ? 1 : 0), m_rec1 = __ballot(hit && !on_plane ? 1 : 0);
+    const unsigned long long m_c0 = __ballot(do_refl && on_plane ? 1 : 0), m_c1 = __ballot(do_refl && !on_plane ? 1 : 0), m_c2 = __ballot(do_refr ? 1 : 0);
+    unsigned (*s_rec)[16] = s_rec2[parity];
+    unsigned (*s_child)[16] = s_child2[parity];
     parity ^= 1u;
-    if (lane == 0) { s_rec[wave] = (unsigned)__popcll(m_rec); s_child[wave] = (unsigned)(__popcll(m_refl) + __popcll(m_refr)); }
+    if (lane == 0) {
+      s_rec[0][wave] = (unsigned)__popcll(m_rec0); s_rec[1][wave] = (unsigned)__popcll(m_rec1);
+      s_child[0][wave] = (unsigned)__popcll(m_c0); s_child[1][wave] = (unsigned)__popcll(m_c1); s_child[2][wave] = (unsigned)__popcll(m_c2);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
       unsigned tr = 0, tc = 0;
-      for (int w = 0; w < n_waves; w++) { tr += s_rec[w]; tc += s_child[w]; }
+      for (int w = 0; w < n_waves; w++) { tr += s_rec[0][w] + s_rec[1][w]; tc += s_child[0][w] + s_child[1][w] + s_child[2][w]; }
       unsigned br = tr ? atomicAdd(&W.counts[RTC_WF_SHADE_COUNT + level], tr) : 0u;
       unsigned bc = tc ? atomicAdd(&W.counts[level + 1], tc) : 0u;
       if ((unsigned long long)br + tr > W.cap || (unsigned long long)bc + tc > W.cap) { W.counts[RTC_WF_OVERFLOW] = 1u; stats->wf_overflow = 1ull; }
-      for (int w = 0; w < n_waves; w++) {
-        unsigned r = s_rec[w], c = s_child[w];
-        s_rec[w] = br; s_child[w] = bc;
-        br += r; bc += c;
-      }
+      for (int k = 0; k < 2; k++)
+        for (int w = 0; w < n_waves; w++) { unsigned r = s_rec[k][w]; s_rec[k][w] = br; br += r; }
+      for (int k = 0; k < 3; k++)
+        for (int w = 0; w < n_waves; w++) { unsigned c = s_child[k][w]; s_child[k][w] = bc; bc += c; }
     }
     __syncthreads();
-    const unsigned s = s_rec[wave] + (unsigned)__popcll(m_rec & lt);
-    const unsigned jr = s_child[wave] + (unsigned)__popcll(m_refl & lt);
-    const unsigned jt = s_child[wave] + (unsigned)__popcll(m_refl) + (unsigned)__popcll(m_refr & lt);
+    const unsigned s = on_plane ? s_rec[0][wave] + (unsigned)__popcll(m_rec0 & lt) : s_rec[1][wave] + (unsigned)__popcll(m_rec1 & lt);
+    const unsigned jr = on_plane ? s_child[0][wave] + (unsigned)__popcll(m_c0 & lt) : s_child[1][wave] + (unsigned)__popcll(m_c1 & lt);
+    const unsigned jt = s_child[2][wave] + (unsigned)__popcll(m_c2 & lt);
     if (hit && s < W.cap) {
       double* r = W.sr;
       r[s] = st.px; r[cap + s] = st.py; r[2 * cap + s] = st.pz;
