@@ -354,7 +354,7 @@ def measure(args, rtm, dist, workload, fuel, steps, warmup, F, rank, world_size,
                 pf = pm["per_frame"]
                 fetch, write = pf["FETCH_SIZE"] * cal["fetch_bytes_per_unit"], pf["WRITE_SIZE"] * cal["write_bytes_per_unit"]
                 roof["traffic"] = fetch + write
-                roof["traffic_detail"] = {"fetch_bytes": fetch, "write_bytes": write, "calibration": cal, "l2_hit_rate": pf["TCC_HIT_sum"] / max(1.0, pf["TCC_HIT_sum"] + pf["TCC_MISS_sum"]),
+                roof["traffic_detail"] = {"fetch_bytes": fetch, "write_bytes": write, "calibration": {"fetch_bytes_per_unit": cal["fetch_bytes_per_unit"], "write_bytes_per_unit": cal["write_bytes_per_unit"], "source": "profiles/pmc_calibration.json (scripts/pmc_calibrate.sh: measured on known byte counts)"}, "l2_hit_rate": pf["TCC_HIT_sum"] / max(1.0, pf["TCC_HIT_sum"] + pf["TCC_MISS_sum"]),
                                           "source": "rocprofv3 --kernel-trace --pmc, two passes run by this bench invocation; per frame = mean per dispatch x dispatches per frame, per kernel"}
                 roof["hbm_traffic_frac"] = (fetch + write) / (seq_ms * 1e-3) / (HBM_PEAK_GBS * 1e9)
                 busy_cycles = 4.0 * pf["SQ_ACTIVE_INST_VALU"]   # the SQ counts quad-cycles
