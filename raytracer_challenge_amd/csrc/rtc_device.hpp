@@ -1731,11 +1731,14 @@ __device__ __forceinline__ void wf_shadow_rec(const DScene& S, const DCamera& ca
 #define RTC_WF_TS_WAVES 3  // waves per SIMD the traversal kernel is compiled for: 168 VGPRs, no scratch.  At 4 (128 VGPRs) the ray and the
                            // leaf record spill around every leaf test: same frame time, +1.7 GB of HBM traffic per frame (profiles/r2_*)
 #endif
+#ifndef RTC_WF_TS_WAVES_MAXFEAT
+#define RTC_WF_TS_WAVES_MAXFEAT 1  // feature levels up to this one are compiled for RTC_WF_TS_WAVES waves per SIMD, the others for 2
+#endif
 #ifndef RTC_LDS_BLOCK
 #define RTC_LDS_BLOCK (256 * RTC_WF_TS_WAVES)  // LDSC kernels: one block per CU with all the waves the register budget allows
 #endif
 template <bool COUNT, int FEAT, bool KOPS, bool LDSC = false>
-__global__ void __launch_bounds__(LDSC ? RTC_LDS_BLOCK : RTC_BLOCK, FEAT <= 1 ? RTC_WF_TS_WAVES : 2) wf_ts(DScene S, DCamera cam, DPixelMap pm, DWave W, int tl, int sl, unsigned n0, int slot, int fuel_left,
+__global__ void __launch_bounds__(LDSC ? RTC_LDS_BLOCK : RTC_BLOCK, FEAT <= RTC_WF_TS_WAVES_MAXFEAT ? RTC_WF_TS_WAVES : 2) wf_ts(DScene S, DCamera cam, DPixelMap pm, DWave W, int tl, int sl, unsigned n0, int slot, int fuel_left,
                                                                      double* __restrict__ hit_t, int* __restrict__ hit_prim, int* __restrict__ hit_k, DStats* __restrict__ stats) {
   RTC_LDS_STACK(lds_stack);
   LdsScene L = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
