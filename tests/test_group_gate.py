@@ -1,0 +1,94 @@
+"""Group-box gates (BoundingBox::intersects, src/bounding_box.rs:80-92): the device settles rays that miss or cross a group's box by a
+wide margin with approximate quotients (rtc_device.hpp group_box_hit) and evaluates the reference's expression for the rest.  Rays aimed
+AT the faces, edges and corners of every group box of a scene, and nudged off them by 0 ... 1e-5, are the ones in between: their hit
+records must stay bit-exact against the oracle (which restates the reference's expression and nothing else)."""
+import numpy as np
+import pytest
+
+import cases
+from foreign_flattener import RsGroup, build
+from parity import assert_ray_parity
+from raytracer_challenge_amd import scenes
+
+
+def group_boxes(world):
+    out = []
+
+    def walk(node):
+        if isinstance(node, RsGroup):
+            lo, hi = np.array(node.bbox.lo, dtype=float), np.array(node.bbox.hi, dtype=float)
+            if np.isfinite(lo).all() and np.isfinite(hi).all() and (hi > lo).all():
+                out.append((lo, hi))
+            for c in node.children:
+                walk(c)
+
+    for e in world.elements:
+        walk(build(e))
+    return out
+
+
+def grazing_rays(world, per_box=96, seed=5):
+    rng = np.random.default_rng(seed)
+    rays = []
+    for lo, hi in group_boxes(world):
+        size = hi - lo
+        for _ in range(per_box):
+            # a point on the box surface: each coordinate at lo, hi or inside; at least one at a face
+            pick = rng.integers(0, 3, 3)
+            if (pick == 2).all():
+                pick[rng.integers(0, 3)] = rng.integers(0, 2)
+            p = np.where(pick == 0, lo, np.where(pick == 1, hi, lo + rng.uniform(0, 1, 3) * size))
+            o = lo - size * rng.uniform(0.5, 3.0, 3) * rng.choice([-1.0, 1.0], 3) + size * (rng.choice([-1.0, 1.0], 3) > 0)
+            d = p - o
+            d /= np.linalg.norm(d)
+            nudge = rng.choice([0.0, 1e-16, 1e-13, 1e-10, 1e-8, 1e-7, 1e-6, 1e-5])
+            d = d + nudge * rng.normal(size=3)
+            d /= np.linalg.norm(d)
+            if rng.random() < 0.25:   # a direction component around the reference's EPSILON threshold
+                d[rng.integers(0, 3)] = rng.uniform(-3e-5, 3e-5)
+            rays.append(np.concatenate([o, d]))
+            # and the ray that runs IN a face plane of the box
+            q = p.copy()
+            axis = int(np.argmax(pick != 2))
+            d2 = rng.normal(size=3)
+            d2[axis] = 0.0
+            d2 /= np.linalg.norm(d2)
+            rays.append(np.concatenate([q - d2 * size.max() * 2.0, d2]))
+    return np.array(rays)
+
+
+SCENES = {
+    "chapter14_benchmark": lambda: scenes.chapter14_benchmark(64, 48),   # nested, axis-aligned groups
+    "synthetic_grouped_cones": lambda: scenes.synthetic_analytic(n_primitives=64, seed=3, cones=True, grouped=True, hsize=64, vsize=36),
+    "teapot_low": lambda: scenes.chapter15_teapot("teapot_low.obj", 64, 36),
+}
+
+
+def test_the_generator_finds_boxes():
+    for name, make in SCENES.items():
+        cam, world = make()
+        if name != "teapot_low":   # (the OBJ loader's groups are built natively: no Python-side tree to read boxes from)
+            assert len(group_boxes(world)) >= 1, name
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from emu_lib import emu as _emu
+    return _emu()
+
+
+@pytest.mark.parametrize("name", ["chapter14_benchmark", "synthetic_grouped_cones"])
+def test_grazing_rays_in_the_emulator(emu, orc, name):
+    cam, world = SCENES[name]()
+    rays = grazing_rays(world)
+    assert rays.shape[0] >= 96
+    assert_ray_parity(emu, orc, world, rays, 3, label=name + ": rays grazing group boxes")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["chapter14_benchmark", "synthetic_grouped_cones"])
+@pytest.mark.parametrize("kernel", ["1", "4"])
+def test_hip_grazing_rays(hip, orc, name, kernel, monkeypatch):
+    monkeypatch.setenv("RTC_KERNEL", kernel)
+    cam, world = SCENES[name]()
+    assert_ray_parity(hip, orc, world, grazing_rays(world, per_box=256), 3, label=name + ": rays grazing group boxes, path " + kernel)
