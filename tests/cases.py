@@ -29,6 +29,21 @@ def nested_glass():
     return _cam(64, 40, 1.1, (0.5, 1.0, -7)), World([PointLight(Color.white(), Vector.point(-10, 10, -10)), PointLight(Color.new(0.3, 0.3, 0.5), Vector.point(8, 6, -4))], els)
 
 
+def glass_cluster(n=40, seed=21):
+    """Forty overlapping glass spheres, cubes, closed cylinders and cones in a 4-unit box: hit points inside several shapes at once
+    (container lists of depth > 2), enough bounded primitives for the analytic BVH's light grids, and every kind of BVH leaf on the
+    container passes (spheres and cubes are skipped there unless the hit point is inside their box)."""
+    rng = np.random.default_rng(seed)
+    els = [Element.plane(ShapeArgs(transform=Matrix.translation(0, -3, 0), material=Material(pattern=Pattern.checkers(Matrix.id(), Pattern.plain(Color.white()), Pattern.plain(Color.new(0.2, 0.2, 0.2))))))]
+    for i in range(n):
+        t = Matrix.translation(*rng.uniform(-2, 2, 3)) * Matrix.rotation_y(rng.uniform(0, 6.28)) * Matrix.rotation_x(rng.uniform(0, 6.28)) * Matrix.scaling(*([rng.uniform(0.5, 1.5)] * 3))
+        mat = Material(pattern=Pattern.plain(Color.new(*rng.uniform(0.05, 0.3, 3))), diffuse=0.3, transparency=0.85, reflective=0.3, refractive_index=float(rng.choice([1.0, 1.2, 1.5, 2.0])))
+        args = ShapeArgs(transform=t, material=mat)
+        k = i % 4
+        els.append(Element.sphere(args) if k == 0 else Element.cube(args) if k == 1 else Element.cylinder(args, -0.7, 0.8, True) if k == 2 else Element.cone(args, -1.0, 0.5, True))
+    return _cam(48, 32, 1.0, (0.5, 1.0, -9)), World([PointLight(Color.white(), Vector.point(-10, 10, -10)), PointLight(Color.new(0.4, 0.4, 0.6), Vector.point(1.0, 0.5, 0.2))], els)
+
+
 def all_primitives():
     """Every Geometry variant incl. open/closed cylinders and cones, triangles, shadowless shapes, Debug pattern."""
     m = lambda r, g, b, **kw: Material(pattern=Pattern.plain(Color.new(r, g, b)), **kw)

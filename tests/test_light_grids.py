@@ -68,6 +68,27 @@ def test_light_inside_a_primitive_and_degenerate_shadow_rays(emu, orc, monkeypat
     assert_parity(emu, orc, world, cam, 2, label="lights inside bounds / on a surface")
 
 
+def test_overlapping_glass_in_the_emulator(emu, orc, monkeypatch):
+    """cases.glass_cluster: container lists several shapes deep, a light INSIDE the cluster (so inside many primitives' bounds),
+    light grids on / off, both paths, against the oracle."""
+    import cases
+    cam, world = cases.glass_cluster()
+    both_ways(emu, world, cam, 4, monkeypatch)
+    for k in ("1", "4"):
+        monkeypatch.setenv("RTC_KERNEL", k)
+        assert_parity(emu, orc, world, cam, 4, label="glass cluster, path " + k)
+
+
+@pytest.mark.gpu
+def test_hip_overlapping_glass(hip, orc, monkeypatch):
+    import cases
+    cam, world = cases.glass_cluster()
+    both_ways(hip, world, cam, 6, monkeypatch)
+    for k in ("1", "4"):
+        monkeypatch.setenv("RTC_KERNEL", k)
+        assert_parity(hip, orc, world, cam, 6, label="glass cluster, path " + k)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cones,grouped", [(False, False), (True, True)])
 def test_hip_light_grids_are_results_neutral(hip, orc, monkeypatch, cones, grouped):
