@@ -712,6 +712,7 @@ int render_multi(rtc_multi* m, const rtc_camera* cam, int32_t fuel, double* rgb_
       stats->rays_refract += st.rays_refract; stats->rays_container += st.rays_container; stats->accel_nodes += st.accel_nodes; stats->group_tests += st.group_tests;
       stats->tri_tests += st.tri_tests; stats->analytic_tests += st.analytic_tests; stats->nan_ts += st.nan_ts; stats->n_launches += st.n_launches;
       stats->accel_nodes_kernarg += st.accel_nodes_kernarg; stats->analytic_tests_kernarg += st.analytic_tests_kernarg;
+      stats->light_grid_cells += st.light_grid_cells;
       stats->kernel_ms = std::max(stats->kernel_ms, st.kernel_ms);
     }
     HIP_OK(hipSetDevice(s->device));

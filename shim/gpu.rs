@@ -139,6 +139,7 @@ pub struct RtcStats {
     pub _pad: u32,
     pub accel_nodes_kernarg: u64,
     pub analytic_tests_kernarg: u64,
+    pub light_grid_cells: u64,
 }
 
 pub enum RtcScene {}
