@@ -369,6 +369,16 @@ def measure(args, rtm, dist, workload, fuel, steps, warmup, F, rank, world_size,
                                 "profiled clocks are lower than 2.4 GHz, so the busy fraction is a lower bound",
                     "per_kernel": pm["per_kernel"],
                 }
+    else:
+        # N ranks: the frame rank 0 gathered (every rank's interleaved rows, de-interleaved) against the same frame rendered by rank 0's
+        # device alone through rtc_render — the frame the N = 1 line checks against the oracle
+        single, _ = hip.render(nw, cam, fuel, want_hits=False)
+        gathered = fg.image.detach().cpu().numpy().reshape(-1, 3)
+        res["parity"] = {"pixels": int(H * V), "gathered_frame_equals_single_gpu_frame": bool(np.array_equal(gathered, single)),
+                         "max_abs_drgb_vs_single_gpu_frame": float(np.abs(gathered - single).max()),
+                         "checked": "rank 0's gathered, de-interleaved frame of the timed path against rtc_render of the whole frame on rank 0's device; "
+                                    "the oracle comparison of that frame is the parity block of the N = 1 line"}
+    if world_size == 1:
         # PCIe-inclusive figure: Image::par_render semantically returns host pixels (rtc_render: kernel + 24 B/px D2H)
         hip.render(nw, cam, fuel, want_hits=False)
         t1 = time.perf_counter()

@@ -26,6 +26,8 @@ def test_bench_gpus_2_launches_its_own_ranks():
     """`python bench.py --gpus 2` with WORLD_SIZE unset: two ranks are started by bench.py itself, rank 0 prints the one line."""
     j = run_bench("--gpus", "2", "--workload", "smoke", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1
+    # the N-rank line proves its frame too: gathered rows == the whole frame rendered by one rank
+    assert j["parity"]["gathered_frame_equals_single_gpu_frame"] is True and j["parity"]["pixels"] == 64 * 36
     assert j["config"]["process_group"] == {"world_size": 2, "backend": "gloo"}
     assert j["config"]["frames_in_flight"] == 3 and j["scaling"] == "strong" and j["value"] > 0
     assert "STAND-IN" in j["data"]
