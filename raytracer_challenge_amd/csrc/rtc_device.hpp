@@ -157,7 +157,13 @@ __device__ __forceinline__ void cube_axis(double origin, double direction, doubl
 // used where a decision tolerates far more than that and the exact expression is evaluated otherwise.
 __device__ __forceinline__ double approx_rcp(double x) {
 #ifdef RTC_EMU
-  return 1.0 / x;
+  // the CPU emulation of the kernels gives the reciprocal the error the hardware instruction may have (+-2^-23, pseudo-random per
+  // operand), so that the CPU parity tests exercise the margins of every decision built on it
+  unsigned long long bits;
+  __builtin_memcpy(&bits, &x, 8);
+  bits = (bits ^ (bits >> 29)) * 0x9E3779B97F4A7C15ull;
+  const double e = ((double)(bits >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0) * 1.1920928955078125e-07;
+  return (1.0 / x) * (1.0 + e);
 #else
   return __builtin_amdgcn_rcp(x);
 #endif

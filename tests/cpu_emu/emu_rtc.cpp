@@ -82,6 +82,13 @@ static void to_dcam(const rtc_camera& c, DCamera* d) {
 }
 
 extern "C" {
+
+// test hooks: device functions of the kernel source, called directly (tests/test_group_gate.py)
+int rtc_emu_group_box_hit(const double* box6, const double* ray6) {
+  Ray r{ray6[0], ray6[1], ray6[2], ray6[3], ray6[4], ray6[5]};
+  return group_box_hit(box6, r) ? 1 : 0;
+}
+
 const char* rtc_last_error(void) { return g_err.c_str(); }
 int rtc_device_count(void) { return 0; }
 int rtc_scene_create(const rtc_scene_desc* desc, int, rtc_scene** out) {

@@ -92,3 +92,67 @@ def test_hip_grazing_rays(hip, orc, name, kernel, monkeypatch):
     monkeypatch.setenv("RTC_KERNEL", kernel)
     cam, world = SCENES[name]()
     assert_ray_parity(hip, orc, world, grazing_rays(world, per_box=256), 3, label=name + ": rays grazing group boxes, path " + kernel)
+
+
+def reference_box_intersects(lo, hi, o, d):
+    """BoundingBox::intersects (src/bounding_box.rs:80-106) restated: check_axis with the |d| >= EPSILON rule, f64::max / min that
+    ignore a NaN operand, `t_min <= t_max`."""
+    import math
+    EPS = 0.00001
+
+    def axis(origin, direction, mn, mx):
+        a_num, b_num = mn - origin, mx - origin
+        if abs(direction) >= EPS:
+            a, b = a_num / direction, b_num / direction
+        else:
+            a = a_num * math.inf if a_num != 0.0 else math.nan
+            b = b_num * math.inf if b_num != 0.0 else math.nan
+        return (b, a) if a > b else (a, b)
+
+    def fmax(a, b):
+        return b if a != a else (a if b != b else max(a, b))
+
+    def fmin(a, b):
+        return b if a != a else (a if b != b else min(a, b))
+
+    xs, ys, zs = (axis(o[k], d[k], lo[k], hi[k]) for k in range(3))
+    return fmax(fmax(xs[0], ys[0]), zs[0]) <= fmin(fmin(xs[1], ys[1]), zs[1])
+
+
+def test_the_gate_decides_like_the_reference_on_adversarial_rays(emu):
+    """group_box_hit of the kernel source itself (emulator hook; its reciprocals carry the hardware's +-2^-23 error) against the
+    reference's rule: rays through corners, edges and faces of boxes, nudged by 0 ... 1e-5, axis-parallel, with components around
+    EPSILON.  100 000 rays; one wrong answer would mean a margin is too small."""
+    import ctypes as C
+    lib = emu.lib
+    lib.rtc_emu_group_box_hit.restype = C.c_int
+    lib.rtc_emu_group_box_hit.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    rng = np.random.default_rng(11)
+    wrong = 0
+    n_hit = 0
+    for trial in range(100000):
+        c = rng.uniform(-20, 20, 3)
+        size = rng.uniform(0.01, 10, 3)
+        lo, hi = c - size, c + size
+        pick = rng.integers(0, 3, 3)
+        p = np.where(pick == 0, lo, np.where(pick == 1, hi, lo + rng.uniform(0, 1, 3) * 2 * size))
+        o = c + rng.normal(size=3) * rng.uniform(1, 50)
+        d = p - o
+        d /= np.linalg.norm(d)
+        d = d + rng.choice([0.0, 1e-16, 1e-13, 1e-10, 1e-8, 3e-8, 1e-7, 3e-7, 1e-6, 1e-5]) * rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        m = trial % 8
+        if m == 0:
+            d[rng.integers(0, 3)] = rng.uniform(-3e-5, 3e-5)
+        elif m == 1:
+            k = rng.integers(0, 3)
+            d[k] = 0.0
+            o[k] = rng.choice([lo[k], hi[k], lo[k] + rng.uniform(0, 1) * 2 * size[k]])
+        box = (C.c_double * 6)(*lo, *hi)
+        ray = (C.c_double * 6)(*o, *d)
+        got = bool(lib.rtc_emu_group_box_hit(box, ray))
+        want = reference_box_intersects(lo, hi, o, d)
+        n_hit += want
+        wrong += got != want
+    assert wrong == 0
+    assert 20000 < n_hit < 95000   # (the generator produces both answers)
