@@ -156,3 +156,4 @@ def test_the_gate_decides_like_the_reference_on_adversarial_rays(emu):
         wrong += got != want
     assert wrong == 0
     assert 20000 < n_hit < 95000   # (the generator produces both answers)
+
