@@ -185,6 +185,9 @@ int rtc_multi_create(const rtc_scene_desc* desc, const int* devices, int n_devic
 void rtc_multi_destroy(rtc_multi*);
 int rtc_multi_device_count(const rtc_multi*);
 int rtc_render_multi(rtc_multi*, const rtc_camera*, int32_t fuel, double* rgb, rtc_stats* stats);
+/* Same, quantised (Color::clamp, src/color.rs:42-46 — what Image::ppm writes): every replica quantises its own rows on its own
+ * device, so 3 bytes per pixel cross xGMI instead of 24.  rgb8: hsize*vsize*3 bytes (host), row-major. */
+int rtc_render_multi_rgb8(rtc_multi*, const rtc_camera*, int32_t fuel, uint8_t* rgb8, rtc_stats* stats);
 /* Same, image left on the first listed device (rgb_dev: hsize*vsize*3 doubles there).  Asynchronous unless sync != 0: queue
  * several frames, then rtc_multi_sync() waits for all replicas and returns (and clears) their error state. */
 int rtc_render_multi_device(rtc_multi*, const rtc_camera*, int32_t fuel, double* rgb_dev, int sync);

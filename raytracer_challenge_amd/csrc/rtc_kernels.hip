@@ -316,6 +316,22 @@ __global__ void __launch_bounds__(256) rtc_deinterleave_kernel(const double* __r
     image[i] = slab[((unsigned long long)(y % n) * max_rows + y / n) * rowlen + x];
   }
 }
+// The same for quantised tiles (rtc_render_multi_rgb8: every replica quantises its own rows, so 3 bytes per pixel cross xGMI, not 24).
+__global__ void __launch_bounds__(256) rtc_deinterleave8_kernel(const unsigned char* __restrict__ slab, unsigned char* __restrict__ image, unsigned rowlen, unsigned vsize,
+                                                                unsigned n, unsigned max_rows) {
+  const unsigned long long total = (unsigned long long)vsize * rowlen;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * blockDim.x) {
+    const unsigned y = (unsigned)(i / rowlen), x = (unsigned)(i % rowlen);
+    image[i] = slab[((unsigned long long)(y % n) * max_rows + y / n) * rowlen + x];
+  }
+}
+void rtc_launch_deinterleave8(const unsigned char* slab, unsigned char* image, unsigned rowlen, unsigned vsize, unsigned n, unsigned max_rows, hipStream_t stream) {
+  const unsigned long long total = (unsigned long long)vsize * rowlen;
+  if (total == 0) return;
+  unsigned long long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(rtc_deinterleave8_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slab, image, rowlen, vsize, n, max_rows);
+}
 void rtc_launch_deinterleave(const double* slab, double* image, unsigned rowlen, unsigned vsize, unsigned n, unsigned max_rows, hipStream_t stream) {
   const unsigned long long total = (unsigned long long)vsize * rowlen;
   if (total == 0) return;

@@ -20,6 +20,7 @@ void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, 
                       DStats* stats, bool count, hipStream_t stream, bool big_scene);
 void rtc_launch_quantize(const double* rgb, unsigned char* out, unsigned long long n, hipStream_t stream);
 void rtc_launch_deinterleave(const double* slab, double* image, unsigned rowlen, unsigned vsize, unsigned n, unsigned max_rows, hipStream_t stream);
+void rtc_launch_deinterleave8(const unsigned char* slab, unsigned char* image, unsigned rowlen, unsigned vsize, unsigned n, unsigned max_rows, hipStream_t stream);
 void rtc_launch_wavefront(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, const DWave& W, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
                           DStats* stats, bool count, hipStream_t stream, unsigned blocks, unsigned shade_blocks);
 uint64_t rtc_wavefront_work(const DCamera& cam, const DPixelMap& pm);
@@ -636,6 +637,12 @@ struct rtc_multi {
   double* slab = nullptr;           // first device: n x max_rows x hsize x 3
   double* image = nullptr;          // first device: vsize x hsize x 3
   uint64_t slab_cap = 0, image_cap = 0;
+  // rtc_render_multi_rgb8: the same buffers for quantised pixels (a replica quantises its tile on its own device)
+  std::vector<uint8_t*> tiles8;
+  std::vector<uint64_t> tile8_cap;
+  uint8_t* slab8 = nullptr;
+  uint8_t* image8 = nullptr;
+  uint64_t slab8_cap = 0, image8_cap = 0;
 };
 
 namespace {
@@ -652,7 +659,8 @@ int ensure_tuned(rtc_scene* s, const DCamera& dc, const DPixelMap& pm, int fuel,
   return RTC_OK;
 }
 
-int render_multi(rtc_multi* m, const rtc_camera* cam, int32_t fuel, double* rgb_dev_out, double* rgb_host, rtc_stats* stats, bool sync) {
+int render_multi(rtc_multi* m, const rtc_camera* cam, int32_t fuel, double* rgb_dev_out, double* rgb_host, rtc_stats* stats, bool sync, uint8_t* rgb8_host = nullptr) {
+  const bool q8 = rgb8_host != nullptr;
   if (!m || !cam) return rtc_fail(RTC_ERR_INVALID, "NULL argument");
   if (cam->hsize == 0 || cam->vsize == 0) return rtc_fail(RTC_ERR_INVALID, "empty camera");
   const uint32_t n = (uint32_t)m->scenes.size();
@@ -673,16 +681,40 @@ int render_multi(rtc_multi* m, const rtc_camera* cam, int32_t fuel, double* rgb_
       HIP_OK(hipMalloc((void**)&m->tiles[k], max_rows * rowlen * sizeof(double)));
       m->tile_cap[k] = max_rows * rowlen;
     }
+    if (q8 && max_rows * rowlen > m->tile8_cap[k]) {
+      HIP_OK(hipSetDevice(s->device));
+      HIP_OK(hipStreamSynchronize(s->stream));
+      (void)hipFree(m->tiles8[k]);
+      m->tiles8[k] = nullptr; m->tile8_cap[k] = 0;
+      HIP_OK(hipMalloc((void**)&m->tiles8[k], max_rows * rowlen));
+      m->tile8_cap[k] = max_rows * rowlen;
+    }
   }
   HIP_OK(hipSetDevice(s0->device));
-  if ((uint64_t)n * max_rows * rowlen > m->slab_cap) {
+  if (q8) {
+    if ((uint64_t)n * max_rows * rowlen > m->slab8_cap) {
+      HIP_OK(hipStreamSynchronize(s0->stream));
+      (void)hipFree(m->slab8);
+      m->slab8 = nullptr; m->slab8_cap = 0;
+      HIP_OK(hipMalloc((void**)&m->slab8, (uint64_t)n * max_rows * rowlen));
+      m->slab8_cap = (uint64_t)n * max_rows * rowlen;
+    }
+    if (V * rowlen > m->image8_cap) {
+      HIP_OK(hipStreamSynchronize(s0->stream));
+      (void)hipFree(m->image8);
+      m->image8 = nullptr; m->image8_cap = 0;
+      HIP_OK(hipMalloc((void**)&m->image8, V * rowlen));
+      m->image8_cap = V * rowlen;
+    }
+  }
+  if (!q8 && (uint64_t)n * max_rows * rowlen > m->slab_cap) {
     HIP_OK(hipStreamSynchronize(s0->stream));
     (void)hipFree(m->slab);
     m->slab = nullptr; m->slab_cap = 0;
     HIP_OK(hipMalloc((void**)&m->slab, (uint64_t)n * max_rows * rowlen * sizeof(double)));
     m->slab_cap = (uint64_t)n * max_rows * rowlen;
   }
-  if (!rgb_dev_out && V * rowlen > m->image_cap) {
+  if (!q8 && !rgb_dev_out && V * rowlen > m->image_cap) {
     HIP_OK(hipStreamSynchronize(s0->stream));
     (void)hipFree(m->image);
     m->image = nullptr; m->image_cap = 0;
@@ -716,6 +748,10 @@ int render_multi(rtc_multi* m, const rtc_camera* cam, int32_t fuel, double* rgb_
       stats->kernel_ms = std::max(stats->kernel_ms, st.kernel_ms);
     }
     HIP_OK(hipSetDevice(s->device));
+    if (q8) {  // Color::clamp on the replica's own device, behind its trace kernels
+      rtc_launch_quantize(m->tiles[k], m->tiles8[k], rows * rowlen, s->stream);
+      HIP_OK(hipGetLastError());
+    }
     HIP_OK(hipEventRecord(m->done[k], s->stream));
   }
   // gather: the first device's stream waits for each tile and pulls it over xGMI into its slot of the slab, then one
@@ -726,16 +762,20 @@ int render_multi(rtc_multi* m, const rtc_camera* cam, int32_t fuel, double* rgb_
     if (rows == 0) continue;
     rtc_scene* s = m->scenes[k];
     HIP_OK(hipStreamWaitEvent(s0->stream, m->done[k], 0));
-    double* dst = m->slab + (uint64_t)k * max_rows * rowlen;
-    if (s->device == s0->device) HIP_OK(hipMemcpyAsync(dst, m->tiles[k], rows * rowlen * sizeof(double), hipMemcpyDeviceToDevice, s0->stream));
-    else HIP_OK(hipMemcpyPeerAsync(dst, s0->device, m->tiles[k], s->device, rows * rowlen * sizeof(double), s0->stream));
+    void* dst = q8 ? (void*)(m->slab8 + (uint64_t)k * max_rows * rowlen) : (void*)(m->slab + (uint64_t)k * max_rows * rowlen);
+    const void* src = q8 ? (const void*)m->tiles8[k] : (const void*)m->tiles[k];
+    const uint64_t bytes = rows * rowlen * (q8 ? 1 : sizeof(double));
+    if (s->device == s0->device) HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s0->stream));
+    else HIP_OK(hipMemcpyPeerAsync(dst, s0->device, src, s->device, bytes, s0->stream));
     HIP_OK(hipEventRecord(m->copied[k], s0->stream));
     m->copied_valid[k] = 1;
   }
-  rtc_launch_deinterleave(m->slab, image, (unsigned)rowlen, (unsigned)V, n, (unsigned)max_rows, s0->stream);
+  if (q8) rtc_launch_deinterleave8(m->slab8, m->image8, (unsigned)rowlen, (unsigned)V, n, (unsigned)max_rows, s0->stream);
+  else rtc_launch_deinterleave(m->slab, image, (unsigned)rowlen, (unsigned)V, n, (unsigned)max_rows, s0->stream);
   HIP_OK(hipGetLastError());
+  if (q8) HIP_OK(hipMemcpyAsync(rgb8_host, m->image8, V * rowlen, hipMemcpyDeviceToHost, s0->stream));
   if (rgb_host) HIP_OK(hipMemcpyAsync(rgb_host, image, V * rowlen * sizeof(double), hipMemcpyDeviceToHost, s0->stream));
-  if (!sync && !rgb_host) return RTC_OK;
+  if (!sync && !rgb_host && !q8) return RTC_OK;
   HIP_OK(hipStreamSynchronize(s0->stream));
   for (uint32_t k = 0; k < n; k++) {
     int rc = rtc_scene_check(m->scenes[k]);   // error state of every replica's launches
@@ -745,7 +785,7 @@ int render_multi(rtc_multi* m, const rtc_camera* cam, int32_t fuel, double* rgb_
       pm.n = rows * H; pm.mode = 2; pm.row_first = k; pm.row_step = n;
       rc = run(m->scenes[k], dc, pm, fuel, m->tiles[k], false, nullptr, false, true);
       if (rc != RTC_OK) return rc;
-      return render_multi(m, cam, fuel, rgb_dev_out, rgb_host, stats, true);
+      return render_multi(m, cam, fuel, rgb_dev_out, rgb_host, stats, true, rgb8_host);
     }
     if (rc != RTC_OK) return rc;
   }
@@ -764,6 +804,8 @@ int rtc_multi_create(const rtc_scene_desc* desc, const int* devices, int n_devic
     m->scenes.push_back(s);
     m->tiles.push_back(nullptr);
     m->tile_cap.push_back(0);
+    m->tiles8.push_back(nullptr);
+    m->tile8_cap.push_back(0);
     hipEvent_t e = nullptr;
     if (hipSetDevice(devices[k]) != hipSuccess || hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
       rtc_multi_destroy(m.release());
@@ -797,6 +839,7 @@ void rtc_multi_destroy(rtc_multi* m) {
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (k < m->tiles.size()) (void)hipFree(m->tiles[k]);
+    if (k < m->tiles8.size()) (void)hipFree(m->tiles8[k]);
     if (k < m->done.size() && m->done[k]) (void)hipEventDestroy(m->done[k]);
   }
   for (hipEvent_t c : m->copied) if (c) (void)hipEventDestroy(c);
@@ -804,6 +847,8 @@ void rtc_multi_destroy(rtc_multi* m) {
     (void)hipSetDevice(m->scenes[0]->device);
     (void)hipFree(m->slab);
     (void)hipFree(m->image);
+    (void)hipFree(m->slab8);
+    (void)hipFree(m->image8);
   }
   for (rtc_scene* s : m->scenes) rtc_scene_destroy(s);
   delete m;
@@ -814,6 +859,11 @@ int rtc_multi_device_count(const rtc_multi* m) { return m ? (int)m->scenes.size(
 int rtc_render_multi(rtc_multi* m, const rtc_camera* cam, int32_t fuel, double* rgb, rtc_stats* stats) {
   if (!rgb) return rtc_fail(RTC_ERR_INVALID, "NULL argument");
   return render_multi(m, cam, fuel, nullptr, rgb, stats, true);
+}
+
+int rtc_render_multi_rgb8(rtc_multi* m, const rtc_camera* cam, int32_t fuel, uint8_t* rgb8, rtc_stats* stats) {
+  if (!rgb8) return rtc_fail(RTC_ERR_INVALID, "NULL argument");
+  return render_multi(m, cam, fuel, nullptr, nullptr, stats, true, rgb8);
 }
 
 int rtc_render_multi_device(rtc_multi* m, const rtc_camera* cam, int32_t fuel, double* rgb_dev, int sync) {

@@ -158,6 +158,8 @@ extern "C" {
     fn rtc_multi_create(desc: *const RtcSceneDesc, devices: *const c_int, n_devices: c_int, out: *mut *mut RtcMulti) -> c_int;
     fn rtc_multi_destroy(multi: *mut RtcMulti);
     fn rtc_render_multi(multi: *mut RtcMulti, camera: *const RtcCamera, fuel: i32, rgb: *mut f64, stats: *mut RtcStats) -> c_int;
+    #[allow(dead_code)] // Color::clamp'ed pixels (what Image::ppm writes): 3 bytes per pixel cross xGMI instead of 24
+    fn rtc_render_multi_rgb8(multi: *mut RtcMulti, camera: *const RtcCamera, fuel: i32, rgb8: *mut u8, stats: *mut RtcStats) -> c_int;
 }
 
 #[derive(Debug)]

@@ -172,6 +172,14 @@ def test_hip_render_multi_equals_one_device(hip, devices):
         assert st.pixels == n and st.rays_primary == n
         rgb2 = np.full((n, 3), np.nan)
         assert lib.rtc_render_multi(m, C.byref(rc), 5, rgb2.ctypes.data, None) == 0, lib.rtc_last_error()   # the timed form: no counters
+        # the quantised form (each replica quantises its rows, 3 B/px gathered): Color::clamp of the f64 image, byte for byte
+        lib.rtc_render_multi_rgb8.restype = C.c_int
+        lib.rtc_render_multi_rgb8.argtypes = [vp, C.POINTER(ff.RtcCamera), C.c_int32, vp, C.POINTER(RtcStatsC)]
+        rgb8 = np.zeros(rgb.size, dtype=np.uint8)
+        assert lib.rtc_render_multi_rgb8(m, C.byref(rc), 5, rgb8.ctypes.data, None) == 0, lib.rtc_last_error()
+        c = np.where(np.isnan(rgb.reshape(-1)), 1.0, np.minimum(rgb.reshape(-1), 1.0))
+        want8 = np.floor(np.maximum(c, 0.0) * 255.0 + 0.5).astype(np.uint8)   # round half away from zero on non-negative values
+        assert np.array_equal(rgb8, want8), (devices, int((rgb8 != want8).sum()))
         assert np.array_equal(rgb2, want_rgb), (name, devices)
         out = torch.full((n * 3,), float("nan"), dtype=torch.float64, device="cuda:0")
         for _ in range(3):                                                                                     # frames queued back to back
