@@ -158,6 +158,11 @@ struct DScene {
   int32_t has_csg;           // 1: the program contains an OP_CSG
   int32_t has_groups;        // 0: no gates; 1: only OP_MESH / OP_CSG ops are gated; 2: individual primitives are gated
   int32_t csg_max_hits;      // most intersections one top-level CSG subtree can produce
+  // Cube quirk rays without a scan (scene_build.hpp, cube_pad): a ray with 48 m^2 <= reach^2 |d|^2 — m = |origin - centre|_inf + radius of
+  // the analytic BVH's frame — cannot report a cube intersection outside the padded leaf boxes, so the leaves test it like any other
+  // ray and the cubes' OP_QGRID / OP_QUIRK (c = 1) is skipped.  quirk_reach2 = reach^2 / 48, 0: feature off.
+  double quirk_reach2;
+  double abvh_frame[4];
   int32_t light_grid_n, light_grid_cell_off;  // the light grids' common n and light 0's cell_off (light l: + l * (6 n^2 + 1))
   int32_t light_grid_first;  // 0 or 1 + index in qgrids of light 0's light grid (= the b of the program's OP_BVH)
   int32_t has_recs;          // 1: some op reads intersection records (pisect): analytic BVH, quirk scans, primitives outside the kernel arguments

@@ -98,6 +98,8 @@ struct Trav {
   int best_prim, best_k, best_klast;
   int shadowed;
   int unordered;  // any-hit pass that skips the nearest-first ordering of a node's children
+  int cubes_in_leaf;  // 1: this ray's reach is short enough for the padded cube boxes (DScene.quirk_reach2): BVH leaves test cubes for
+                      // quirk rays too and the cubes' quirk scan is skipped; set by traverse()
   int light;      // shadow passes: index of the light the ray runs towards (its light grid may stand in for the BVH walk), the ray's
                   // length in c1_t; else -1
   double c1_t, c2_t;
@@ -465,7 +467,7 @@ __device__ __forceinline__ void visit_prim(const DScene& S, int prim, const Ray&
   Ray o = to_object(m, r);
   if (policy == 1) {
     bool quirk = false;
-    if (P.geom == 2) quirk = fabs(o.dx) < EPS || fabs(o.dy) < EPS || fabs(o.dz) < EPS;
+    if (P.geom == 2) quirk = !T.cubes_in_leaf && (fabs(o.dx) < EPS || fabs(o.dy) < EPS || fabs(o.dz) < EPS);
     else if (P.geom == 4) quirk = fabs((o.dx * o.dx - o.dy * o.dy + o.dz * o.dz) - 0.0) < EPS;
     if (quirk) return;
   }
@@ -856,6 +858,12 @@ __device__ __noinline__ int csg_eval(const DScene& S, int pc, const Ray& r, Trav
 template <int FEAT, bool KOPS, int MODE = -1, bool LDSC = false>
 __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T, Counters& C, int* __restrict__ stack, int stride, const LdsScene& L = LdsScene{}) {
   if (MODE >= 0) T.mode = MODE;
+  T.cubes_in_leaf = 0;
+  if (S.quirk_reach2 > 0.0) {
+    const double m = fmax(fmax(fabs(r.ox - S.abvh_frame[0]), fabs(r.oy - S.abvh_frame[1])), fabs(r.oz - S.abvh_frame[2])) + S.abvh_frame[3];
+    const double len2 = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
+    T.cubes_in_leaf = (len2 >= 0.0025 && m * m <= S.quirk_reach2 * len2) ? 1 : 0;  // (a NaN anywhere: 0, the scan)
+  }
   const LightCell lcell = light_grid_fetch<MODE>(S, r, T);
   if (KOPS) {
     for (int pc = 0; pc < S.n_kops; pc++) {
@@ -887,6 +895,8 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
         } else {
           visit_prim<FEAT, LDSC>(S, op.a, r, T, C, 0, L);
         }
+      } else if ((op.op == OP_QUIRK || op.op == OP_QGRID) && op.c == 1 && T.cubes_in_leaf) {
+        // the cubes' quirk scan: this ray's leaves have tested them
       } else if (op.op == OP_QUIRK) {
         for (int i = op.a; i < op.a + op.b; i++) visit_prim<FEAT, LDSC>(S, S.quirk_prim[i], r, T, C, 2, L);
       } else if (op.op == OP_QGRID) {
@@ -934,6 +944,8 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
     if (op.op == OP_PRIM) {
       visit_prim<FEAT, LDSC>(S, op.a, r, T, C, 0, L);
       pc++;
+    } else if ((op.op == OP_QUIRK || op.op == OP_QGRID) && op.c == 1 && T.cubes_in_leaf) {
+      pc++;  // the cubes' quirk scan: this ray's leaves have tested them
     } else if (op.op == OP_QUIRK) {
       for (int i = op.a; i < op.a + op.b; i++) visit_prim<FEAT, LDSC>(S, S.quirk_prim[i], r, T, C, 2, L);
       pc++;
@@ -1254,6 +1266,7 @@ __device__ __forceinline__ void reset_closest(Trav& T, int mode) {
   T.shadowed = 0;
   T.unordered = 0;
   T.light = -1;
+  T.cubes_in_leaf = 0;
   T.c1_t = 0.0; T.c2_t = 0.0; T.c1_prim = -1; T.c2_prim = -1;
   T.g_known = 0ull; T.g_pass = 0ull;
 }

@@ -348,6 +348,8 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     d.has_groups = hv.has_groups;
     d.has_recs = hv.has_recs;
     d.light_grid_first = hv.light_grid_first;
+    d.quirk_reach2 = hv.quirk_reach2;
+    std::memcpy(d.abvh_frame, hv.abvh_frame, sizeof(d.abvh_frame));
     d.light_grid_n = hv.light_grid_n; d.light_grid_cell_off = hv.light_grid_cell_off;
     d.csg_max_hits = hv.csg_max_hits;
     d.csg_slab = nullptr;

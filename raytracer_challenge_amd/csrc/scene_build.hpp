@@ -42,13 +42,20 @@ struct ProgramBuilder {
 
   static constexpr size_t kMinAccel = 6;  // fewer bounded children than this stay a linear list
 
-  bool local_bounds(const rtc_prim& p, double lo[3], double hi[3]) const {
+  // Cubes in the analytic BVH are padded by cube_pad object units: a ray with an object-space direction component below EPSILON is
+  // treated as parallel to that slab pair (src/shape.rs:641-648), so the points it reports drift out of the cube by up to |t| EPSILON
+  // along that axis.  With the pad, every such point of a ray whose reach |t| stays below cube_pad / EPSILON is inside the leaf's box:
+  // those rays (all rays of a scene a few hundred units across) need no separate quirk scan for cubes (rtc_device.hpp, cubes_in_leaf).
+  double cube_pad = 0.015625;
+  bool local_bounds(const rtc_prim& p, double lo[3], double hi[3], bool for_accel = false) const {
     // bounds of every point the exact test can report, in object space (tighter than Geometry::bbox for open
     // cylinders, whose walls only exist for min < y < max: src/shape.rs:745,756)
     switch (p.geometry) {
       case RTC_SPHERE:
-      case RTC_CUBE:
         for (int a = 0; a < 3; a++) { lo[a] = -1.0; hi[a] = 1.0; }
+        return true;
+      case RTC_CUBE:
+        for (int a = 0; a < 3; a++) { lo[a] = -1.0 - (for_accel ? cube_pad : 0.0); hi[a] = 1.0 + (for_accel ? cube_pad : 0.0); }
         return true;
       case RTC_PLANE: return false;
       case RTC_CYLINDER:
@@ -74,7 +81,7 @@ struct ProgramBuilder {
 
   bool world_bounds(const rtc_prim& p, bvh::Item* out) const {
     double lo[3], hi[3];
-    if (!local_bounds(p, lo, hi)) return false;
+    if (!local_bounds(p, lo, hi, true)) return false;
     rth::M4 inv = rth::M4::from(D.xforms[p.xform].transform_inv), fwd;
     if (!inv.invert(&fwd)) return false;
     const double(*F)[4] = fwd.a;
@@ -385,6 +392,8 @@ struct ProgramBuilder {
   }
 
   int csg_max_hits = 0;
+  bool have_abvh = false;        // an analytic BVH with padded cubes exists: its frame (centre, inf-norm radius) bounds a ray's reach
+  double abvh_frame[4] = {0, 0, 0, 0};
   size_t n_plain_items = (size_t)-1;  // items[0, n_plain_items) are primitive indices (quirk lists, quirk-grid cells); the rest light-grid pairs
   std::vector<int32_t>& items_member() { return this->items; }
   bvh::DeviceBuildFn device_build = nullptr;  // set by rtc_scene_create when the accelerator is to be built on the device
@@ -483,12 +492,20 @@ struct ProgramBuilder {
         root = direct(root);
         const size_t bvh_op = ops.size();
         ops.push_back({OP_BVH, root, 0, fi, -1, {0, 0, 0}});
-        int32_t q0 = (int32_t)quirk_prim.size();
-        for (int32_t pi : ids)
-          if (D.prims[pi].geometry == RTC_CUBE || D.prims[pi].geometry == RTC_CONE) quirk_prim.push_back(pi);
-        int32_t qn = (int32_t)quirk_prim.size() - q0;
-        if (qn >= kMinQuirkGrid) ops.push_back({OP_QGRID, build_quirk_grid(q0, qn), 0, 0, -1, {0, 0, 0}});
-        else if (qn > 0) ops.push_back({OP_QUIRK, q0, qn, 0, -1, {0, 0, 0}});
+        // quirk lists: cubes and cones apart — c = 1 marks the cubes' op, which a ray of short reach skips (cube_pad above)
+        for (int kind = 0; kind < 2; kind++) {
+          int32_t q0 = (int32_t)quirk_prim.size();
+          for (int32_t pi : ids)
+            if (D.prims[pi].geometry == (kind == 0 ? RTC_CUBE : RTC_CONE)) quirk_prim.push_back(pi);
+          int32_t qn = (int32_t)quirk_prim.size() - q0;
+          const int32_t tag = (kind == 0 && cube_pad > 0.0) ? 1 : 0;
+          if (qn >= kMinQuirkGrid) ops.push_back({OP_QGRID, build_quirk_grid(q0, qn), 0, tag, -1, {0, 0, 0}});
+          else if (qn > 0) ops.push_back({OP_QUIRK, q0, qn, tag, -1, {0, 0, 0}});
+        }
+        if (cube_pad > 0.0) {
+          have_abvh = true;
+          std::memcpy(abvh_frame, &bvh_frame[(size_t)fi * 4], sizeof(abvh_frame));
+        }
         // light grids last: their {reference, distance} pairs form the tail of the item array, after every plain primitive index
         n_plain_items = items_member().size();
         if (root >= 0) ops[bvh_op].b = build_light_grids(items, ids);  // (a root that is itself a leaf needs no help)
@@ -572,6 +589,7 @@ struct HostArrays {
   std::vector<DPat> pats;
   std::vector<double> lights;
   int32_t n_lights = 0, all_cast_shadow = 1, bvh_depth = 0, bvh_stack = 8, csg_max_hits = 0, built_on_device = 0;
+  double quirk_reach2 = 0.0, abvh_frame[4] = {0, 0, 0, 0};  // see DScene
 
   // DScene.kops / kplanes (device_scene.h): a short, jump-free program travels in the kernel arguments.
   void fill_kernarg_program(DScene& d) const {
@@ -627,6 +645,8 @@ struct HostArrays {
     for (int32_t pi : bvh_prims) if (prims[pi].gcond >= 0) d.has_groups = 2;
     for (const DOp& o : ops) { if (o.op == OP_MESH) d.has_mesh = 1; if (o.op == OP_CSG) d.has_csg = 1; }
     fill_kernarg_program(d);
+    d.quirk_reach2 = quirk_reach2;
+    std::memcpy(d.abvh_frame, abvh_frame, sizeof(d.abvh_frame));
     d.light_grid_first = 0;
     for (const DOp& o : ops) if (o.op == OP_BVH && o.b > 0) d.light_grid_first = o.b;
     d.light_grid_n = 0; d.light_grid_cell_off = 0;
@@ -657,6 +677,16 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
   lap("validate");
   ProgramBuilder pb{D};
   pb.device_build = device_build;
+  if (const char* e = std::getenv("RTC_CUBE_PAD")) pb.cube_pad = std::max(0.0, std::atof(e));
+  for (uint32_t i = 0; i < D.n_prims && pb.cube_pad > 0.0; i++) {  // the reach argument needs |t| EPSILON s << |t| |d| (s = the cube's scale)
+    if (D.prims[i].geometry != RTC_CUBE) continue;
+    rth::M4 inv = rth::M4::from(D.xforms[D.prims[i].xform].transform_inv), fwd;
+    if (!inv.invert(&fwd)) { pb.cube_pad = 0.0; break; }
+    for (int c = 0; c < 3; c++) {
+      const double nrm = std::sqrt(fwd.a[0][c] * fwd.a[0][c] + fwd.a[1][c] * fwd.a[1][c] + fwd.a[2][c] * fwd.a[2][c]);
+      if (!(nrm < 1e3)) pb.cube_pad = 0.0;
+    }
+  }
   if (const char* e = std::getenv("RTC_DEVICE_BVH_MIN")) pb.device_build_min = (size_t)std::strtoull(e, nullptr, 10);
   if (!pb.emit(0, D.n_nodes) || pb.status != RTC_OK) { *err = pb.error; return pb.status != RTC_OK ? pb.status : RTC_ERR_INVALID; }
   lap("program + BVH build");
@@ -722,6 +752,11 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
   H->mtri_prim = std::move(pb.mtri_prim);
   H->items = std::move(pb.items);
   H->n_plain_items = pb.n_plain_items;
+  if (pb.have_abvh && pb.cube_pad > 0.0) {
+    const double reach = pb.cube_pad / 0.00001;   // |t| below which a parallel-axis point stays inside the pad
+    H->quirk_reach2 = reach * reach / 48.0;       // the ray-side test is 4 sqrt(3) m / |d| <= reach (rtc_device.hpp)
+    std::memcpy(H->abvh_frame, pb.abvh_frame, sizeof(H->abvh_frame));
+  }
   H->bvh_prims = std::move(pb.bvh_prims);
   H->qgrids = std::move(pb.qgrids);
   H->qcell = std::move(pb.qcell);
