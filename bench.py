@@ -397,7 +397,7 @@ def measure(args, rtm, dist, workload, fuel, steps, warmup, F, rank, world_size,
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=240, help="timed frames (default 240: >= 0.5 s of device time at ~2.4 ms/frame)")
+    ap.add_argument("--steps", type=int, default=300, help="timed frames (default 300: >= 0.5 s of device time at ~2 ms/frame)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="config2")
     ap.add_argument("--fuel", type=int, default=None, help="recursion depth (default: 5; 8 for config4/config5)")
