@@ -756,6 +756,8 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
     const double reach = pb.cube_pad / 0.00001;   // |t| below which a parallel-axis point stays inside the pad
     H->quirk_reach2 = reach * reach / 48.0;       // the ray-side test is 4 sqrt(3) m / |d| <= reach (rtc_device.hpp)
     std::memcpy(H->abvh_frame, pb.abvh_frame, sizeof(H->abvh_frame));
+    if (timing) std::fprintf(stderr, "[rtc-timing]   cube pad %.6f: rays with |o - (%.2f, %.2f, %.2f)|_inf + %.2f <= %.1f |d| skip the cubes' quirk scan\n", pb.cube_pad,
+                             pb.abvh_frame[0], pb.abvh_frame[1], pb.abvh_frame[2], pb.abvh_frame[3], std::sqrt(H->quirk_reach2));
   }
   H->bvh_prims = std::move(pb.bvh_prims);
   H->qgrids = std::move(pb.qgrids);
