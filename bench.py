@@ -155,7 +155,8 @@ def pmc_measure(workload, fuel, path, timeout_s=240):
         out = tempfile.mkdtemp(prefix="rtc_pmc_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
                "--pmc-child", "--workload", workload, "--fuel", str(fuel), "--steps", "3", "--warmup", "1", "--inflight", "1"]
-        env = dict(os.environ, TMPDIR="/tmp")
+        # the child renders with the parent's device path (no tuning launches of its own under the profiler)
+        env = dict(os.environ, TMPDIR="/tmp", RTC_KERNEL="4" if "wavefront" in path else "1")
         try:
             p = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
         except subprocess.TimeoutExpired:
@@ -224,6 +225,127 @@ def parity_block(idx, ref_rgb, ref_hits, gpu_rgb_full, gpu_hits_full, timed_fram
             "checked": "full frame rendered through rtc_render on the device path of the timed region, compared with the oracle on the cpu_baseline sample"}
 
 
+def host_pixel_times(hip, dr, nw, cam, fuel, reps=5):
+    """ms per blocking host-pixel render of the whole frame (the drop-in call), median of `reps`."""
+    import ctypes as C
+    import numpy as np
+    from raytracer_challenge_amd.device import RtcCameraC, RtcStatsC
+    lib = hip.lib
+    lib.rtc_render.restype = C.c_int
+    lib.rtc_render.argtypes = [C.c_void_p, C.POINTER(RtcCameraC), C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rtc_render_rgb8.restype = C.c_int
+    lib.rtc_render_rgb8.argtypes = [C.c_void_p, C.POINTER(RtcCameraC), C.c_int32, C.c_void_p, C.c_void_p]
+    n = cam.hsize * cam.vsize
+    from raytracer_challenge_amd.backend import HIT_DTYPE
+
+    def timed(fn):
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            fn()
+            ts.append((time.perf_counter() - t) * 1e3)
+        return float(np.median(ts))
+
+    def call(rgb, hits):
+        rc = lib.rtc_render(dr.scene, C.byref(dr.cam), fuel, None, 0, n, rgb.ctypes.data, hits.ctypes.data if hits is not None else None, None)
+        if rc != 0:
+            raise SystemExit("rtc_render: %s" % lib.rtc_last_error())
+
+    def call8(buf):
+        rc = lib.rtc_render_rgb8(dr.scene, C.byref(dr.cam), fuel, buf.ctypes.data, None)
+        if rc != 0:
+            raise SystemExit("rtc_render_rgb8: %s" % lib.rtc_last_error())
+
+    keep_rgb, keep_hits, keep8 = np.zeros((n, 3)), np.zeros(n, dtype=HIT_DTYPE), np.zeros(3 * n, dtype=np.uint8)
+    call(keep_rgb, keep_hits)
+    call8(keep8)
+    out = {
+        "f64_fresh_buffer_ms": timed(lambda: call(np.empty((n, 3)), None)),
+        "f64_reused_buffer_ms": timed(lambda: call(keep_rgb, None)),
+        "f64_with_hits_fresh_buffers_ms": timed(lambda: call(np.empty((n, 3)), np.empty(n, dtype=HIT_DTYPE))),
+        "rgb8_fresh_buffer_ms": timed(lambda: call8(np.empty(3 * n, dtype=np.uint8))),
+        "rgb8_reused_buffer_ms": timed(lambda: call8(keep8)),
+        "bytes": {"f64": 24 * n, "hits": 16 * n, "rgb8": 3 * n},
+        "note": "wall clock of the blocking C-ABI call (kernels + copy to the caller's pageable memory), median of %d; fresh = a new numpy.empty "
+                "destination per call (no pages yet: the library touches them from host threads while the device renders)" % reps,
+    }
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's own call pattern: one par_render per process (src/bin/*.rs: build the world, render once at 4096x2160, exit).
+# Measured in a fresh child process (cold code objects, no warm allocator): OBJ parse + flatten + accelerator build + upload,
+# the first render's kernels, the copy to host memory.
+# ---------------------------------------------------------------------------------------------------------------------
+ONE_SHOT = {"config3_4096x2160": ("config3", 4096, 2160), "config2": ("config2", 1920, 1080)}
+
+
+def one_shot_child(name):
+    import ctypes as C
+    import numpy as np
+    t_start = time.perf_counter()
+    import raytracer_challenge_amd as rt
+    from raytracer_challenge_amd import scenes
+    from raytracer_challenge_amd.device import DeviceRenderer, RtcCameraC, RtcStatsC
+    workload, H, V = ONE_SHOT[name]
+    if workload == "config3":
+        cam, world = scenes.chapter15_teapot("teapot_low.obj", H, V)
+    else:
+        cam, world, _ = make_workload(workload)
+    fuel = default_fuel(workload)
+    hip = rt.hip_backend()
+    t0 = time.perf_counter()
+    nw = hip.build_world(world)              # host mirror: Shape::shape, composite, parse_obj (the OBJ file is read and parsed here)
+    t1 = time.perf_counter()
+    dr = DeviceRenderer(hip, nw, cam)        # flatten + accelerator build + upload (first HIP call of the process: context creation)
+    t2 = time.perf_counter()
+    lib = hip.lib
+    lib.rtc_render.restype = C.c_int
+    lib.rtc_render.argtypes = [C.c_void_p, C.POINTER(RtcCameraC), C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(RtcStatsC)]
+    n = H * V
+    rgb = np.empty((n, 3))
+    st = RtcStatsC()
+    t3 = time.perf_counter()
+    rc = lib.rtc_render(dr.scene, C.byref(dr.cam), fuel, None, 0, n, rgb.ctypes.data, None, None)
+    t4 = time.perf_counter()
+    if rc != 0:
+        raise SystemExit("rtc_render: %s" % lib.rtc_last_error())
+    pi = dr.path_info()
+    # the same call again (warm): what the first call paid on top (code object load, scratch, queues, page faults)
+    rgb2 = np.empty((n, 3))
+    t5 = time.perf_counter()
+    lib.rtc_render(dr.scene, C.byref(dr.cam), fuel, None, 0, n, rgb2.ctypes.data, None, None)
+    t6 = time.perf_counter()
+    lib.rtc_render(dr.scene, C.byref(dr.cam), fuel, None, 0, n, rgb2.ctypes.data, None, C.byref(st))   # counting variant: device time of the kernels
+    obj_parse_ms = None
+    if workload == "config3":
+        import ctypes
+        lib.rtw_parse_obj.restype = ctypes.c_void_p
+        tp = time.perf_counter()
+        e = hip._element(world.elements[-1], {}, []) if world.elements[-1].tag == "obj" else None
+        obj_parse_ms = (time.perf_counter() - tp) * 1e3 if e else None
+    print(json.dumps({"one_shot": name, "hsize": H, "vsize": V, "fuel": fuel,
+                      "import_ms": (t0 - t_start) * 1e3, "build_world_ms": (t1 - t0) * 1e3, "create_ms": (t2 - t1) * 1e3,
+                      "first_render_to_host_ms": (t4 - t3) * 1e3, "second_render_to_host_ms": (t6 - t5) * 1e3,
+                      "kernel_ms_counting_variant": st.kernel_ms, "obj_parse_ms": obj_parse_ms,
+                      "total_ms": (t4 - t0) * 1e3, "first_launch_path": "wavefront" if st.n_launches > 1 else "one kernel", "path_info": pi,
+                      "equal": bool(np.array_equal(rgb, rgb2))}), flush=True)
+
+
+def one_shot_measure(timeout_s=300):
+    out = {}
+    for name in ONE_SHOT:
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--one-shot-child", name], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+            line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            out[name] = json.loads(line[-1]) if line else {"error": (p.stderr or "")[-300:]}
+        except Exception as e:  # a failed side measurement must not lose the headline line
+            out[name] = {"error": repr(e)}
+    out["note"] = ("fresh child process per entry: build_world = host mirror incl. OBJ parse; create = flatten + accelerator + upload (+ HIP context); "
+                   "first_render_to_host = one blocking rtc_render of the whole frame into a new host buffer; total = build_world + create + first render")
+    return out
+
+
 class Runtime:
     """Where tiles live and how the device is synchronised.  The product runtime is the GPU (librtc_amd.so, HIP streams, RCCL).
     RTC_BENCH_CPU_STANDIN=1 (tests/test_bench_cpu.py only) swaps in the CPU emulator of the kernel source (tests/cpu_emu, test
@@ -280,7 +402,7 @@ def measure(args, rtm, dist, workload, fuel, steps, warmup, F, rank, world_size,
         for i in range(k):
             if i >= F:
                 finish(i - F)
-            drs[i % F].render_rows_async(fuel, rank, world_size, fg.n_rows, fg.tiles[i % F])
+            drs[i % F].render_rows_async(fuel, rank, world_size, fg.n_rows, fg.tiles[i % F], band_rows=fg.band_rows)
             drs[i % F].record(0)
         for i in range(max(0, k - F), k):
             finish(i)
@@ -293,14 +415,14 @@ def measure(args, rtm, dist, workload, fuel, steps, warmup, F, rank, world_size,
             d.sync()
 
     # untimed: counting variant -> unique rays + work counters of this rank's launch
-    cst = dr.render_rows(fuel, rank, world_size, fg.n_rows, fg.tiles[0], count=True, sync=True)
+    cst = dr.render_rows(fuel, rank, world_size, fg.n_rows, fg.tiles[0], count=True, sync=True, band_rows=fg.band_rows)
     rays_local = torch.tensor([float(cst["unique_rays"])], dtype=torch.float64, device=gather_dev)
     if world_size > 1:
         dist.all_reduce(rays_local)
     rays_total = float(rays_local.item())
 
     # untimed: both device paths measured twice per renderer, the faster one kept
-    paths = [d.tune(fuel, rank, world_size, fg.n_rows, fg.tiles[j]) for j, d in enumerate(drs)]
+    paths = [d.tune(fuel, rank, world_size, fg.n_rows, fg.tiles[j], band_rows=fg.band_rows) for j, d in enumerate(drs)]
     path = paths[0]
     run_frames(warmup)
     for d in drs:
@@ -322,7 +444,7 @@ def measure(args, rtm, dist, workload, fuel, steps, warmup, F, rank, world_size,
     n_seq = max(5, min(50, steps))
     dr.record(2)
     for _ in range(n_seq):
-        dr.render_rows_async(fuel, rank, world_size, fg.n_rows, fg.tiles[0])
+        dr.render_rows_async(fuel, rank, world_size, fg.n_rows, fg.tiles[0], band_rows=fg.band_rows)
     dr.record(3)
     dr.sync()
     dr.check()
@@ -331,7 +453,7 @@ def measure(args, rtm, dist, workload, fuel, steps, warmup, F, rank, world_size,
 
     res = {"workload": workload, "desc": desc, "H": H, "V": V, "fuel": fuel, "steps": steps, "warmup": warmup, "elapsed": elapsed, "rays_total": rays_total,
            "seq_ms": seq_ms, "path": path, "counters": cst, "n_lights": nw.n_lights, "primitives": nw.primitive_count, "info": dr.info(), "F": F}
-    if rank != 0:
+    if rank != 0 or args.pmc_child:
         return res
     alg = algorithmic_bytes(cst, path["path"], nw.primitive_count, lds_tables=dr.info().get("wavefront_lds_bytes_per_block", 0) > 0)
     achieved = alg["memory"] / (seq_ms * 1e-3) / 1e9
@@ -379,13 +501,12 @@ def measure(args, rtm, dist, workload, fuel, steps, warmup, F, rank, world_size,
                          "checked": "rank 0's gathered, de-interleaved frame of the timed path against rtc_render of the whole frame on rank 0's device; "
                                     "the oracle comparison of that frame is the parity block of the N = 1 line"}
     if world_size == 1:
-        # PCIe-inclusive figure: Image::par_render semantically returns host pixels (rtc_render: kernel + 24 B/px D2H)
-        hip.render(nw, cam, fuel, want_hits=False)
-        t1 = time.perf_counter()
-        n_h = 3
-        for _ in range(n_h):
-            rgb_full, hits_full = hip.render(nw, cam, fuel)
-        res["ms_per_step_incl_d2h"] = (time.perf_counter() - t1) / n_h * 1e3
+        # PCIe-inclusive figures: Image::par_render returns host pixels (src/image.rs:76-80).  rtc_render / rtc_render_rgb8 into
+        # a FRESH destination every call (what `-> Image` means: a new Vec whose pages do not exist yet), into a reused one, and
+        # with the primary-hit channel; wall clock around the blocking call.
+        res["host_pixels"] = host_pixel_times(hip, dr, nw, cam, fuel)
+        res["ms_per_step_incl_d2h"] = res["host_pixels"]["f64_fresh_buffer_ms"]
+        rgb_full, hits_full = hip.render(nw, cam, fuel)
         if want_cpu:
             base, idx, ref_rgb, ref_hits = cpu_baseline(world, cam, fuel)
             res["cpu_baseline"] = base
@@ -406,10 +527,15 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC child passes (roofline.traffic = null)")
     ap.add_argument("--extra-workloads", default="config3", help="comma list of further workloads measured in full after the headline one, at N=1")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--one-shot-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--no-one-shot", action="store_true", help="skip the one-shot (fresh process, one render) measurements")
     args = ap.parse_args()
     if args.fuel is None:
         args.fuel = default_fuel(args.workload)
 
+    if args.one_shot_child:
+        one_shot_child(args.one_shot_child)
+        return
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -458,15 +584,17 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic" if not standin else "synthetic; CPU STAND-IN REHEARSAL of the bench plumbing (kernel source emulated on the CPU): not a measurement",
             "config": {"workload": m["desc"], "hsize": H, "vsize": V, "fuel": m["fuel"], "lights": m["n_lights"], "primitives": m["primitives"],
-                       "partition": "rows interleaved by rank, RCCL gather to rank 0" if world_size > 1 else "single GPU",
+                       "partition": "8-row bands dealt round-robin by rank, RCCL gather to rank 0" if world_size > 1 else "single GPU",
                        "frames_in_flight": F, "process_group": {"world_size": world_size, "backend": backend_name},
                        "unique_rays_per_frame": m["rays_total"], "rays_per_pixel": m["rays_total"] / (H * V)},
             "roofline": m["roofline"],
             "accelerator": m["info"],
         }
-        for k in ("valu", "parity", "cpu_baseline", "ms_per_step_incl_d2h"):
+        for k in ("valu", "parity", "cpu_baseline", "ms_per_step_incl_d2h", "host_pixels"):
             if k in m:
                 out[k] = m[k]
+        if world_size == 1 and not args.no_one_shot and not standin:
+            out["one_shot"] = one_shot_measure()
         if world_size == 1:
             for name in [w for w in args.extra_workloads.split(",") if w and w != args.workload]:
                 fuel2 = default_fuel(name)
@@ -474,10 +602,16 @@ def main():
                             want_pmc=not args.no_pmc, want_cpu=not args.no_cpu_baseline)
                 ent = {"workload": e["desc"], "value": e["rays_total"] * e["steps"] / e["elapsed"] / 1e6, "unit": "Mrays/s", "steps": e["steps"],
                        "ms_per_step": e["elapsed"] / e["steps"] * 1e3, "unique_rays_per_frame": e["rays_total"], "roofline": e["roofline"], "accelerator": e["info"]}
-                for k in ("valu", "parity", "cpu_baseline", "ms_per_step_incl_d2h"):
+                for k in ("valu", "parity", "cpu_baseline", "ms_per_step_incl_d2h", "host_pixels"):
                     if k in e:
                         ent[k] = e[k]
                 out[name] = ent
+                # the headline numbers of every further workload inside the object the driver parses
+                out["config"].setdefault("secondary", {})[name] = {
+                    "workload": e["desc"], "value": ent["value"], "unit": "Mrays/s", "ms_per_step": ent["ms_per_step"],
+                    "kernel_ms_sequential": e["seq_ms"], "path": e["path"]["path"], "roofline_frac": e["roofline"]["frac"],
+                    "roofline_achieved_gbs": e["roofline"]["achieved"], "ms_per_step_incl_d2h": e.get("ms_per_step_incl_d2h"),
+                    "parity_max_abs_drgb": (e.get("parity") or {}).get("max_abs_drgb"), "primary_hit_mismatches": (e.get("parity") or {}).get("primary_hit_mismatches")}
         print(json.dumps(out), flush=True)
     if world_size > 1:
         dist.barrier()

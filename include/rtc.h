@@ -147,6 +147,9 @@ typedef struct rtc_stats {
   uint64_t analytic_tests_kernarg; /* of analytic_tests: plane records read from the kernel arguments     */
   uint64_t light_grid_cells;       /* light-grid cells looked up by shadow rays, each instead of a BVH walk (8 B of
                                       offsets + 4 B per candidate)                                         */
+  uint64_t group_tests_uniform;    /* of group_tests: gates of whole meshes named by a kernel-argument program: every lane of
+                                      the wave reads the SAME box (scalar loads of one address), so like the other
+                                      *_kernarg records they move no bytes through the vector memory system */
 } rtc_stats;
 
 const char* rtc_last_error(void);
@@ -165,16 +168,42 @@ uint64_t rtc_scene_device_bytes(const rtc_scene*);
 int rtc_render(rtc_scene*, const rtc_camera*, int32_t fuel, const uint64_t* pixel_indices, uint64_t first, uint64_t n,
                double* rgb, rtc_hit* hits, rtc_stats* stats);
 
+/* Parity channel beyond the primary hit ("hit indices bit-exact" for the whole ray tree): per pixel, the wrapping 64-bit sum over
+ * every ray of its de-duplicated ray tree — the primary ray and every reflected / refracted ray World::color_at spawns, each
+ * once (the reference traces them once per light, src/world.rs:58-79) — of hash(t bits, primitive sequence number, push index of
+ * the ray's nearest hit; ray depth; ray kind), a miss hashing as (0, -1, 0).  The hash is defined in csrc/device_scene.h
+ * (rtc_hit_hash_base / rtc_hit_hash) and restated by the oracle; equal digests mean every closest hit of the pixel's ray tree
+ * agrees bit for bit.  Pixels as in rtc_render; digest: n values (host).  Runs the counting kernel variants. */
+int rtc_render_hit_digest(rtc_scene*, const rtc_camera*, int32_t fuel, const uint64_t* pixel_indices, uint64_t first, uint64_t n, uint64_t* digest);
+
+/* The whole frame, quantised on the device (Color::clamp, src/color.rs:42-46 — what Image::ppm writes): hsize*vsize*3 bytes
+ * (host), row-major; 3 bytes per pixel cross PCIe instead of 24. */
+int rtc_render_rgb8(rtc_scene*, const rtc_camera*, int32_t fuel, uint8_t* rgb8, rtc_stats* stats);
+
+/* Host buffers handed to rtc_render / rtc_render_rgb8 / rtc_render_multi* / rtc_trace_rays are written by the device copy
+ * directly; while the device renders, the library touches their pages from a few host threads (a freshly allocated Vec / calloc
+ * buffer has none yet; RTC_PRETOUCH_THREADS, default 8, 0 = off), so on an error return their contents are unspecified. */
+
 /* Same, output left in device memory (rgb_dev: n*3 doubles on the scene's device), for the rows
  * row_first, row_first+row_step, ... (n_rows of them) — the tile-interleaved multi-GPU partition.
  * Asynchronous on the scene's stream unless `sync` != 0.  count_stats != 0 uses the counting kernel variant. */
 int rtc_render_rows_device(rtc_scene*, const rtc_camera*, int32_t fuel, uint32_t row_first, uint32_t row_step, uint32_t n_rows,
                            double* rgb_dev, rtc_stats* stats, int count_stats, int sync);
 
+/* The partition the multi-device entries use ("8-row strips"): the image is cut into bands of band_rows rows
+ * (the last one may be short) and part band_first of band_step owns bands band_first, band_first + band_step, ...; its dense
+ * tile holds them in order.  A wave of the trace kernels is an 8x8 pixel tile of the DENSE tile, so band_rows = 8 keeps it an 8x8
+ * tile of the image too (band_rows = 1 is rtc_render_rows_device: at 8 parts one wave's pixels then span 64 image rows).
+ * Renders the first n_rows rows of that dense tile (rtc_band_rows_owned() = all of them). */
+int rtc_render_bands_device(rtc_scene*, const rtc_camera*, int32_t fuel, uint32_t band_rows, uint32_t band_first, uint32_t band_step,
+                            uint32_t n_rows, double* rgb_dev, rtc_stats* stats, int count_stats, int sync);
+uint64_t rtc_band_rows_owned(uint64_t vsize, uint32_t band_rows, uint32_t band_first, uint32_t band_step);
+
 /* ---- N GPUs of one process ----------------------------------------------------------------------------------------
  * For the caller of Image::par_render (src/image.rs:65-81) that owns several devices.  An rtc_multi holds one replica of the
  * scene per listed device (a device may be listed more than once — two replicas on one GPU — which is how a one-GPU box
- * exercises the whole path).  rtc_render_multi: replica k traces image rows k, k + n, ... on its own device and stream (no
+ * exercises the whole path).  rtc_render_multi: replica k traces the bands k, k + n, ... of the image (8 rows each unless
+ * rtc_multi_set_band_rows says otherwise; see rtc_render_bands_device) on its own device and stream (no
  * exchange while tracing: pixels are independent, src/image.rs:68-73); the dense tiles are pulled to the FIRST listed device over
  * xGMI (peer copies behind per-replica events), de-interleaved there, and the whole image (hsize*vsize*3 doubles, row-major) is
  * copied to `rgb` (host).  Same pixels, bit for bit, as rtc_render on one device.  stats (optional): counters summed over the
@@ -184,6 +213,8 @@ typedef struct rtc_multi rtc_multi;
 int rtc_multi_create(const rtc_scene_desc* desc, const int* devices, int n_devices, rtc_multi** out);
 void rtc_multi_destroy(rtc_multi*);
 int rtc_multi_device_count(const rtc_multi*);
+/* Rows per band of the partition (default 8; 1 = single rows interleaved).  Waits for queued frames. */
+int rtc_multi_set_band_rows(rtc_multi*, uint32_t band_rows);
 int rtc_render_multi(rtc_multi*, const rtc_camera*, int32_t fuel, double* rgb, rtc_stats* stats);
 /* Same, quantised (Color::clamp, src/color.rs:42-46 — what Image::ppm writes): every replica quantises its own rows on its own
  * device, so 3 bytes per pixel cross xGMI instead of 24.  rgb8: hsize*vsize*3 bytes (host), row-major. */
@@ -241,7 +272,10 @@ uint32_t rtc_scene_wavefront_lds_bytes(const rtc_scene*);
  * RTC_KERNEL=1|4 pins a path for every launch of scenes created afterwards (pixel lists and explicit rays included: the parity
  * tests run both).  With the environment variable RTC_KERNEL unset the library measures: for one launch shape (camera, rows, fuel) the first
  * four SYNCHRONOUS launches alternate between the paths (the smaller of a path's two device times counts: a first launch
- * pays for code loading and scratch), every later launch of that shape takes the faster.  Reports the state for
+ * pays for code loading and scratch), every later launch of that shape takes the faster.  Until a shape is measured — a caller
+ * that renders one frame per scene, asynchronous launches — a guess from the scene decides: wavefront iff it has >= 32 bounded
+ * analytic primitives, >= 10 % of its primitives reflect or refract, fuel >= 2 and the launch has >= 256 K pixels (the one-kernel
+ * path needs no ray queues).  Reports the state for
  * the most recent launch shape: *choice = 0 while undecided, else 1 or 4; the measured device times in ms (< 0 = not yet
  * measured).  Any pointer may be NULL. */
 void rtc_scene_path_info(const rtc_scene*, int32_t* choice, double* one_kernel_ms, double* wavefront_ms);

@@ -128,13 +128,20 @@ struct orc_stats {
   uint64_t nan_seen;     // 1 if a NaN t reached a sort (the reference would panic)
 };
 
+int orc_render_ex(rtw_world* w, const rtw_camera* cam, int fuel, const uint64_t* idx, uint64_t n, double* rgb, rtw_hit* hits,
+                  uint32_t threads, orc_stats* st, uint64_t* digest);
 int orc_render(rtw_world* w, const rtw_camera* cam, int fuel, const uint64_t* idx, uint64_t n, double* rgb, rtw_hit* hits,
                uint32_t threads, orc_stats* st) {
+  return orc_render_ex(w, cam, fuel, idx, n, rgb, hits, threads, st, nullptr);
+}
+// The same pass with the hit-tree digests of the pixels (rt_oracle.hpp World::hit_hash; digest may be NULL).
+int orc_render_ex(rtw_world* w, const rtw_camera* cam, int fuel, const uint64_t* idx, uint64_t n, double* rgb, rtw_hit* hits,
+                  uint32_t threads, orc_stats* st, uint64_t* digest) {
   Matrix m = Matrix::from16(cam->transform), inv;
   if (!m.inverse(&inv)) return fail("camera: singular transform");
   Camera c = Camera::make((size_t)cam->hsize, (size_t)cam->vsize, cam->field_of_view, m);
   static_assert(sizeof(HitRecord) == sizeof(rtw_hit), "hit record layout");
-  RenderResult rr = render_pixels(c, w->w, fuel, idx, (size_t)n, rgb, (HitRecord*)hits, threads);
+  RenderResult rr = render_pixels(c, w->w, fuel, idx, (size_t)n, rgb, (HitRecord*)hits, threads, digest);
   if (st) {
     double L = (double)w->w.lights.size(), unique = 0, traced = 0, div = 1.0;
     for (int d = 0; d < Counters::MAXD; d++) {

@@ -960,11 +960,26 @@ struct World {  // :12-15
     return w;
   }
 
+  // Hit-tree digest (TEST CHANNEL, not a reference concept): the wrapping 64-bit sum, over every ray of the pixel's ray tree
+  // counted ONCE — the reference traces a reflected / refracted subtree once per light (world.rs:58-79); only the first light's
+  // copy is summed — of a hash of the ray's nearest hit (t bits, primitive sequence number, push index; a miss: 0, -1, 0), its
+  // depth and its kind (0 primary, 1 reflected, 2 refracted).  The hash is the one the device states in csrc/device_scene.h
+  // (rtc_hit_hash_base / rtc_hit_hash), restated here; the hits are each side's own.
+  static uint64_t mix64(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x; }
+  static uint64_t hit_hash(uint64_t t_bits, int32_t prim, int32_t push, int depth, int kind) {
+    uint64_t base = mix64(t_bits) ^ ((((uint64_t)(uint32_t)prim << 32) | (uint64_t)(uint32_t)push) * 0x9E3779B97F4A7C15ull);
+    return mix64(base ^ ((uint64_t)(((unsigned)depth << 8) | (unsigned)kind) + 1ull) * 0xD6E8FEB86659FD93ull);
+  }
   struct Ctx {
     Intersections xs;
     bool nan_seen = false;
     Counters* counters = nullptr;
     int fuel0 = FUEL;
+    // digest channel
+    uint64_t* digest = nullptr;                                    // this pixel's accumulator (nullptr = off)
+    const std::vector<std::pair<size_t, int32_t>>* id2seq = nullptr;  // shape id -> DFS sequence number (sorted)
+    int repeat = 0;      // > 0: inside a subtree the reference re-traces for a light other than the first
+    int next_kind = 0;   // kind of the ray the next color_at call traces
   };
 
   void intersect(const Ray& ray, Ctx& c) const {  // :18-24
@@ -984,11 +999,15 @@ struct World {  // :12-15
   Color shade_hit(const State& st, int fuel, Ctx& c) const {  // :50-82
     Color color = Color::black();
     int depth = c.fuel0 - fuel;
+    bool first_light = true;
     for (auto& light : lights) {
       bool shadowed = is_shadowed(light, st.over_point, c, depth < 0 ? 0 : depth);
       Color surface = st.shape->lighting(light, st.over_point, st.eye, st.normal, shadowed);
+      if (!first_light) c.repeat++;   // (digest channel only: marks the re-traced copies)
       Color reflected = reflected_color(st, fuel, c);
       Color refracted = refracted_color(st, fuel, c);
+      if (!first_light) c.repeat--;
+      first_light = false;
       Color extra = (st.shape->material.reflective > 0.0 && st.shape->material.transparency > 0.0)
                         ? reflected * st.reflectance + refracted * (1.0 - st.reflectance)
                         : reflected + refracted;
@@ -999,6 +1018,7 @@ struct World {  // :12-15
   Color reflected_color(const State& st, int fuel, Ctx& c) const {  // :84-102
     if (fuel <= 0 || st.shape->material.reflective == 0.0) return Color::black();
     Ray r{st.over_point, st.reflect};
+    c.next_kind = 1;
     return color_at(r, fuel - 1, c) * st.shape->material.reflective;
   }
   Color refracted_color(const State& st, int fuel, Ctx& c) const {  // :104-132
@@ -1010,6 +1030,7 @@ struct World {  // :12-15
     double cos_t = std::sqrt(1.0 - sin2_t);
     Vector direction = st.normal * (n_ratio * cos_i - cos_t) - st.eye * n_ratio;
     Ray r{st.under_point, direction};
+    c.next_kind = 2;
     return color_at(r, fuel - 1, c) * st.shape->material.transparency;
   }
   // :134-149.  `first` (optional) receives the nearest-hit record of THIS call.
@@ -1020,6 +1041,17 @@ struct World {  // :12-15
     sort_intersections(c.xs, &c.nan_seen);
     const Intersection* h = hit(c.xs);
     if (did_hit) *did_hit = (h != nullptr);
+    if (c.digest && c.repeat == 0) {
+      uint64_t tb = 0;
+      int32_t seq = -1, push = 0;
+      if (h) {
+        std::memcpy(&tb, &h->t, 8);
+        auto it = std::lower_bound(c.id2seq->begin(), c.id2seq->end(), std::make_pair(h->shape->id, (int32_t)INT32_MIN));
+        seq = (it != c.id2seq->end() && it->first == h->shape->id) ? it->second : -2;
+        push = h->push_idx;
+      }
+      *c.digest += hit_hash(tb, seq, push, depth, c.next_kind);
+    }
     if (h) {
       Intersection self = *h;
       if (first) *first = self;
@@ -1098,7 +1130,7 @@ struct RenderResult {
 // image.rs:65-81 over an arbitrary list of pixel indices (i -> x = i % hsize, y = i / hsize), on
 // `threads` std::threads with dynamic chunking (stands in for rayon's work-stealing par_iter).
 inline RenderResult render_pixels(const Camera& cam, const World& world, int fuel, const uint64_t* indices, size_t n,
-                                  double* rgb, HitRecord* hits, unsigned threads) {
+                                  double* rgb, HitRecord* hits, unsigned threads, uint64_t* digest = nullptr) {
   std::vector<const Shape*> order;
   world.number_shapes(order);
   std::vector<std::pair<size_t, int32_t>> id2seq;
@@ -1129,6 +1161,7 @@ inline RenderResult render_pixels(const Camera& cam, const World& world, int fue
         World::Ctx fresh;  // `&mut vec![]` per pixel (image.rs:72)
         fresh.counters = c.counters;
         fresh.fuel0 = fuel;
+        if (digest) { digest[q] = 0; fresh.digest = &digest[q]; fresh.id2seq = &id2seq; fresh.next_kind = 0; }
         Intersection first{};
         bool did = false;
         Color col = world.color_at(ray, fuel, fresh, &first, &did);

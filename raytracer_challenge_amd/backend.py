@@ -199,6 +199,33 @@ class Backend:
         self._check(self.lib.rtw_render(nw.handle, C.byref(cam), int(fuel), idx_p, n, rgb.ctypes.data, hits.ctypes.data if want_hits else None), "render")
         return rgb, hits
 
+    def render_digest(self, nw: NativeWorld, camera: Camera, fuel: int = FUEL, pixel_indices: Optional[np.ndarray] = None, device: int = 0) -> np.ndarray:
+        """include/rtc.h rtc_render_hit_digest: per pixel, the digest of every closest hit of its ray tree (parity channel)."""
+        lib = self.lib
+        lib.rtw_world_scene.restype = C.c_void_p
+        lib.rtw_world_scene.argtypes = [C.c_void_p, C.c_int]
+        lib.rtw_make_camera.restype = C.c_int
+        lib.rtw_make_camera.argtypes = [C.c_void_p, C.c_void_p]
+        lib.rtc_render_hit_digest.restype = C.c_int
+        lib.rtc_render_hit_digest.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+        lib.rtc_last_error.restype = C.c_char_p
+        scene = lib.rtw_world_scene(nw.handle, int(device))
+        if not scene:
+            raise RtwError("scene upload failed: %s" % self._err())
+        cc = self.camera_c(camera)
+        rc_cam = (C.c_double * 21)()   # rtc_camera: 2 x u64 + 3 + 16 doubles
+        if lib.rtw_make_camera(C.byref(cc), C.byref(rc_cam)) != 0:
+            raise RtwError("camera: %s" % self._err())
+        if pixel_indices is None:
+            n, idx_p = camera.hsize * camera.vsize, None
+        else:
+            pixel_indices = np.ascontiguousarray(pixel_indices, dtype=np.uint64)
+            n, idx_p = pixel_indices.size, pixel_indices.ctypes.data
+        out = np.empty(n, dtype=np.uint64)
+        if lib.rtc_render_hit_digest(scene, C.byref(rc_cam), int(fuel), idx_p, 0, n, out.ctypes.data) != 0:
+            raise RtwError("rtc_render_hit_digest: %s" % (lib.rtc_last_error() or b"").decode())
+        return out
+
     def color_at(self, nw: NativeWorld, rays: np.ndarray, fuel: int = FUEL):
         """World::color_at for rays given as rows {ox,oy,oz,dx,dy,dz}.  Returns (rgb[n,3], hits[n])."""
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)

@@ -93,6 +93,8 @@ struct DCsg {
                               // csg_max_hits entries per lane of the launch (the reference's lists are unbounded, src/shape.rs:248-269)
 #define RTC_CSG_MAX_DEPTH 8
 struct DCsgHit { double t; int32_t prim, k; };
+// A pixel's primary-hit record as the C ABI hands it out (include/rtc.h rtc_hit): packed on the device from the kernels' SoA rows.
+struct DHit { double t; int32_t prim, k; };
 
 struct DPrim {  // 32 bytes
   int32_t geom;
@@ -186,8 +188,11 @@ struct DPixelMap {
   uint64_t first;             // unused on device (a contiguous range is issued as mode 2, step 1, or as mode 1)
   const uint64_t* indices;    // mode 1: i = indices[q]
   uint32_t mode;              // 1 list, 2 interleaved rows, 3 explicit rays
-  uint32_t row_first, row_step;  // mode 2: row = row_first + (q / hsize) * row_step, x = q % hsize
+  uint32_t row_first, row_step;  // mode 2: dense row j = q / hsize of the launch is image row (row_first + (j / band) * row_step) * band + j % band,
   const double* rays;         // mode 3: n x {o, d}
+  uint32_t band;              // mode 2: rows per band (0 = 1): row_first / row_step count bands.  Bands of 8 rows keep a wave's 8x8 pixel tile
+  uint32_t pad;               //   contiguous in the image when the rows of a frame are dealt out to several devices
+  unsigned long long* digest; // parity channel (counting variants only; NULL = off): per output slot, the hit-tree digest (rtc_hit_hash below)
 };
 
 struct DCamera {
@@ -203,6 +208,7 @@ struct DStats {  // device-side counters (atomically accumulated per wave)
   unsigned long long knodes;    // of accel_nodes: BVH root nodes read from the kernel arguments (scalar loads, no memory traffic)
   unsigned long long kplanes;   // of analytic_tests: plane records read from the kernel arguments
   unsigned long long light_cells;  // light-grid cells looked up by shadow rays (each in place of a BVH walk)
+  unsigned long long kgroups;   // of group_tests: gates named by a kernel-argument program (one box for the whole wave: scalar loads)
   unsigned long long diag[64];  // RTC_DIAG builds only: region cycles / lane-utilisation sums (scripts/diag_report.py)
   // sticky error state: accumulated over every launch since the last rtc_scene_check() / synchronous read-back, which clear it
   unsigned long long nan_ts;       // NaN intersection t's seen (-> RTC_ERR_NAN)
@@ -214,6 +220,26 @@ struct DStats {  // device-side counters (atomically accumulated per wave)
 #define RTC_STATS_LAUNCH_BYTES offsetof(DStats, nan_ts)
 
 #define RTC_MAX_FUEL 16
+
+// Hit-tree digest (parity channel, include/rtc.h rtc_render_hit_digest): a pixel's digest is the wrapping 64-bit sum, over every
+// ray of its de-duplicated ray tree (the primary ray, every reflected / refracted ray; shadow rays are not hits of the tree), of
+// rtc_hit_hash(closest hit of the ray, depth, kind) — a miss hashes as (t bits 0, primitive -1, push 0).  Device and oracle share
+// this definition only; each computes its own hits.  kind: 0 primary, 1 reflected, 2 refracted.
+#if defined(__HIPCC__) || defined(RTC_EMU)
+#define RTC_HD __host__ __device__
+#else
+#define RTC_HD
+#endif
+static inline RTC_HD unsigned long long rtc_mix64(unsigned long long x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return x;
+}
+static inline RTC_HD unsigned long long rtc_hit_hash_base(unsigned long long t_bits, int32_t prim, int32_t push) {
+  return rtc_mix64(t_bits) ^ ((((unsigned long long)(uint32_t)prim << 32) | (unsigned long long)(uint32_t)push) * 0x9E3779B97F4A7C15ull);
+}
+static inline RTC_HD unsigned long long rtc_hit_hash(unsigned long long base, int depth, int kind) {
+  return rtc_mix64(base ^ ((unsigned long long)(((unsigned)depth << 8) | (unsigned)kind) + 1ull) * 0xD6E8FEB86659FD93ull);
+}
 
 // Wavefront path (rtc_device.hpp / rtc_kernels.hip, wf_* kernels): rays of one bounce level live in a queue; per level a traversal launch
 // (closest hits of the level + shadow rays and lighting of the previous level) and a shading launch (hit state, pattern
@@ -244,6 +270,7 @@ struct DWave {
   uint32_t* counts;     // RTC_WF_COUNTS counters: [level] rays of the level, [32 + level] shade records, [63] overflow flag, [64..] chunk cursors
   uint32_t cap;
   uint32_t pad;
+  unsigned long long* dig;  // hit-tree digest launches only (else NULL; its own allocation): (levels) x cap rtc_hit_hash_base of each ray's closest hit
 };
 // Bytes of the arrays above for `cap` elements per row and `levels` levels, and the carving of one allocation into them (shared
 // by rtc_scene.cpp and the CPU emulator of the kernels).  Per element at fuel 5: 50 doubles + 17 ints = 468 B.
@@ -266,6 +293,7 @@ static inline void dwave_carve(DWave* W, void* mem, uint64_t cap, int levels) {
   W->counts = (uint32_t*)q;
   W->cap = (uint32_t)cap;
   W->pad = 0;
+  W->dig = nullptr;
 }
 #ifndef RTC_BVH_STACK
 #define RTC_BVH_STACK 64

@@ -112,6 +112,7 @@ struct Counters {
   unsigned int accel_nodes, group_tests, tri_tests, analytic_tests, nan_ts;
   unsigned int knodes, kplanes;  // of accel_nodes / analytic_tests: records that came from the kernel arguments (no memory traffic)
   unsigned int light_cells;      // light-grid cells looked up (each in place of a BVH walk)
+  unsigned int kgroups;          // of group_tests: the gate's group came from a kernel-argument op (wave-uniform box address)
 };
 
 // ---- diagnostics (RTC_DIAG builds only; the shipped kernel compiles these to nothing) ----------------------------------
@@ -224,6 +225,15 @@ __device__ __forceinline__ bool groups_pass(const DScene& S, int g, const Ray& r
     g = S.group_parent[g];
   }
   return true;
+}
+
+// The gate of an op of the kernel-argument program: the group index is the same for every lane, so the chain's boxes are read
+// with scalar loads of one address each (counted apart: they move no bytes through the vector memory system).
+__device__ __forceinline__ bool kops_gate(const DScene& S, int g, const Ray& r, Trav& T, Counters& C) {
+  const unsigned before = C.group_tests;
+  const bool pass = groups_pass<false>(S, g, r, T, C);
+  C.kgroups += C.group_tests - before;
+  return pass;
 }
 
 // Ray::transform (src/ray.rs:14-19) with Matrix*Vector (src/linalg/matrix.rs:261-284); origin.w = 1, direction.w = 0.
@@ -907,7 +917,7 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
           quirk_grid_scan<FEAT, LDSC>(S, op.pad[0] >= 0 ? S.kqgrid : S.qgrids[op.a], rr, T, C, L);
         }
         DIAG_SPAN_END(4);
-      } else if (!mesh || FEAT == 0 || op.g < 0 || groups_pass<false>(S, op.g, r, T, C)) {  // OP_MESH / OP_BVH
+      } else if (!mesh || FEAT == 0 || op.g < 0 || kops_gate(S, op.g, r, T, C)) {  // OP_MESH / OP_BVH
         walk = true;
         cur = op.a;
         if (!mesh && light_grid_candidates(S, lcell, T, C, cur, sp, stack, stride)) {
@@ -1346,7 +1356,10 @@ __device__ __forceinline__ Ray slot_ray(const DPixelMap& pm, const DCamera& cam,
   // the host only issues modes 1 (index list), 2 (interleaved rows; a contiguous whole-row range is step 1) and 3 (rays)
   uint64_t i;
   if (pm.mode == 1) i = pm.indices[q];
-  else i = ((uint64_t)pm.row_first + (q / cam.hsize) * pm.row_step) * cam.hsize + (q % cam.hsize);
+  else {
+    const uint64_t j = q / cam.hsize, band = pm.band ? pm.band : 1u;
+    i = (((uint64_t)pm.row_first + (j / band) * pm.row_step) * band + j % band) * cam.hsize + (q % cam.hsize);
+  }
   return camera_ray(cam, i);
 }
 
@@ -1366,7 +1379,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, WAVES ? WAVES : ((FEAT >= 2 && RTC_
   RTC_LDS_STACK(lds_stack);
   int* stack = lds_stack + threadIdx.x;
   const int stride = RTC_BLOCK;
-  Counters C = {0, 0, 0, 0, 0, 0, 0, 0};
+  Counters C = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned n_primary = 0, n_shadow = 0, n_reflect = 0, n_refract = 0, n_container = 0;
   const WorkMap wm = make_workmap(pm, cam);
 #ifdef RTC_DIAG
@@ -1390,6 +1403,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, WAVES ? WAVES : ((FEAT >= 2 && RTC_
     int fuel = fuel0;
     int kind = 0;
     bool first = true;
+    unsigned long long dg = 0ull;  // hit-tree digest (counting variant with pm.digest set)
     const double L = (double)S.n_lights;
 
     for (;;) {
@@ -1401,6 +1415,11 @@ __global__ void __launch_bounds__(RTC_BLOCK, WAVES ? WAVES : ((FEAT >= 2 && RTC_
       traverse<FEAT, KOPS, MODE_CLOSEST>(S, ray, T, C, stack, stride);
       DIAG_REGION(0);
       bool did_hit = T.best_prim != 0x7fffffff;
+      if (COUNT && pm.digest) {
+        unsigned long long tb = 0ull;
+        if (did_hit) __builtin_memcpy(&tb, &T.best_t, 8);
+        dg += rtc_hit_hash(rtc_hit_hash_base(tb, did_hit ? T.best_prim : -1, did_hit ? T.best_k : 0), fuel0 - fuel, kind);
+      }
       if (first) {
         first = false;
         if (hit_t) {
@@ -1535,6 +1554,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, WAVES ? WAVES : ((FEAT >= 2 && RTC_
         rgb[3 * q + 0] = acc_r;
         rgb[3 * q + 1] = acc_g;
         rgb[3 * q + 2] = acc_b;
+        if (COUNT && pm.digest) pm.digest[q] = dg;
         break;
       }
       const Pending& p = pend[--np];
@@ -1566,6 +1586,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, WAVES ? WAVES : ((FEAT >= 2 && RTC_
     atomicAdd(&stats->knodes, (unsigned long long)C.knodes);
     atomicAdd(&stats->kplanes, (unsigned long long)C.kplanes);
     atomicAdd(&stats->light_cells, (unsigned long long)C.light_cells);
+    atomicAdd(&stats->kgroups, (unsigned long long)C.kgroups);
   }
 }
 
@@ -1599,7 +1620,7 @@ __device__ __forceinline__ Ray wf_load_ray(const DWave& W, int level, unsigned i
 template <int FEAT, bool KOPS, bool LDSC>
 __device__ __forceinline__ void wf_trace_ray(const DScene& S, const DCamera& cam, const DPixelMap& pm, const DWave& W, const WorkMap& wm, int level, unsigned i,
                                              double* __restrict__ hit_t, int* __restrict__ hit_prim, int* __restrict__ hit_k, int* stack, int stride, Counters& C,
-                                             unsigned& n_rays, unsigned& n_container, int fuel_left, const LdsScene& L) {
+                                             unsigned& n_rays, unsigned& n_container, int fuel_left, const LdsScene& L, bool digest = false) {
   const size_t cap = W.cap;
   int32_t* ch = W.child + (size_t)level * 2 * cap;
   Ray ray;
@@ -1627,6 +1648,11 @@ __device__ __forceinline__ void wf_trace_ray(const DScene& S, const DCamera& cam
     hit_k[q] = did_hit ? T.best_k : 0;
   }
   W.h_prim[i] = did_hit ? T.best_prim : -1;
+  if (digest) {
+    unsigned long long tb = 0ull;
+    if (did_hit) __builtin_memcpy(&tb, &T.best_t, 8);
+    W.dig[(size_t)level * cap + i] = rtc_hit_hash_base(tb, did_hit ? T.best_prim : -1, did_hit ? T.best_k : 0);
+  }
   // child links: none yet; a miss is marked as such (the gather then knows that no contribution was written for this ray)
   ch[i] = did_hit ? -1 : RTC_WF_MISS; ch[cap + i] = -1;
   if (!did_hit) return;
@@ -1770,7 +1796,7 @@ __global__ void __launch_bounds__(LDSC ? RTC_LDS_BLOCK : RTC_BLOCK, FEAT <= RTC_
     stride = (int)blockDim.x;
   }
 #endif
-  Counters C = {0, 0, 0, 0, 0, 0, 0, 0};
+  Counters C = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned n_rays = 0, n_container = 0, n_shadow = 0;
 #ifdef RTC_DIAG
   if (threadIdx.x < 64) s_diag[threadIdx.x] = 0ull;
@@ -1797,7 +1823,7 @@ __global__ void __launch_bounds__(LDSC ? RTC_LDS_BLOCK : RTC_BLOCK, FEAT <= RTC_
         const unsigned i = base + o + (unsigned)lane;
         if (i < nt) {
           DIAG_SPAN_BEGIN();
-          wf_trace_ray<FEAT, KOPS, LDSC>(S, cam, pm, W, wm, tl, i, hit_t, hit_prim, hit_k, stack, stride, C, n_rays, n_container, fuel_left, L);
+          wf_trace_ray<FEAT, KOPS, LDSC>(S, cam, pm, W, wm, tl, i, hit_t, hit_prim, hit_k, stack, stride, C, n_rays, n_container, fuel_left, L, COUNT && W.dig != nullptr);
           DIAG_SPAN_END(7);
         }
       }
@@ -1829,5 +1855,6 @@ __global__ void __launch_bounds__(LDSC ? RTC_LDS_BLOCK : RTC_BLOCK, FEAT <= RTC_
     atomicAdd(&stats->knodes, (unsigned long long)C.knodes);
     atomicAdd(&stats->kplanes, (unsigned long long)C.kplanes);
     atomicAdd(&stats->light_cells, (unsigned long long)C.light_cells);
+    atomicAdd(&stats->kgroups, (unsigned long long)C.kgroups);
   }
 }

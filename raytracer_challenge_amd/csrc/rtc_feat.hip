@@ -8,6 +8,9 @@
 //   4         3: + CSG                                             memory
 // Exports rtc_launch_trace_v<N> / rtc_launch_wf_ts_v<N> for the dispatchers in rtc_kernels.hip.
 #include "rtc_device.hpp"
+#ifndef RTC_EMU
+#include <atomic>
+#endif
 
 #ifndef RTC_VARIANT
 #error "compile with -DRTC_VARIANT=0..4"
@@ -58,23 +61,37 @@ void RTC_CAT(rtc_launch_wf_ts_v, RTC_VARIANT)(bool count, unsigned grid, hipStre
 #ifndef RTC_EMU
 // The same kernel with the scene's accelerator nodes and intersection records copied into LDS by every block (variants with a
 // kernel-argument program only: those are the small scenes); one block of RTC_LDS_BLOCK threads per CU, `lds_bytes` of dynamic LDS.
-void RTC_CAT(rtc_launch_wf_ts_lds_v, RTC_VARIANT)(bool count, unsigned grid, unsigned lds_bytes, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm,
+// Returns false when this device refuses the dynamic LDS size (nothing was launched: the caller takes the kernel that reads the tables from memory).
+bool RTC_CAT(rtc_launch_wf_ts_lds_v, RTC_VARIANT)(bool count, unsigned grid, unsigned lds_bytes, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm,
                                                   const DWave& W, int tl, int sl, unsigned n0, int slot, int fuel_left, double* hit_t, int* hit_prim, int* hit_k, DStats* stats) {
 #if RTC_VARIANT <= 1
-  static bool raised = false;
-  if (!raised) {  // more than 64 KB of dynamic LDS has to be asked for
+  // More than 64 KB of dynamic LDS has to be asked for, and the attribute belongs to the function object of the CURRENT device:
+  // one bit per device (rtc_multi renders on several from one process), 1 = raised, in the second word 1 = refused.
+  static std::atomic<unsigned long long> raised{0ull}, refused{0ull};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  const unsigned long long bit = 1ull << dev;
+  if (refused.load(std::memory_order_acquire) & bit) return false;
+  if (!(raised.load(std::memory_order_acquire) & bit)) {
     // (static LDS of the kernel — the RTC_DIAG build has some — comes out of the same 160 KB)
     hipFuncAttributes fa;
-    int st = hipFuncGetAttributes(&fa, (const void*)wf_ts<false, RTC_V_FEAT, RTC_V_KOPS, true>) == hipSuccess ? (int)fa.sharedSizeBytes : 0;
-    (void)hipFuncSetAttribute((const void*)wf_ts<true, RTC_V_FEAT, RTC_V_KOPS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - st);
-    (void)hipFuncSetAttribute((const void*)wf_ts<false, RTC_V_FEAT, RTC_V_KOPS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - st);
-    raised = true;
+    const int st = hipFuncGetAttributes(&fa, (const void*)wf_ts<false, RTC_V_FEAT, RTC_V_KOPS, true>) == hipSuccess ? (int)fa.sharedSizeBytes : 0;
+    const hipError_t e1 = hipFuncSetAttribute((const void*)wf_ts<true, RTC_V_FEAT, RTC_V_KOPS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - st);
+    const hipError_t e2 = hipFuncSetAttribute((const void*)wf_ts<false, RTC_V_FEAT, RTC_V_KOPS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - st);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+      (void)hipGetLastError();
+      refused.fetch_or(bit, std::memory_order_acq_rel);
+      return false;
+    }
+    raised.fetch_or(bit, std::memory_order_acq_rel);
   }
   if (count) hipLaunchKernelGGL((wf_ts<true, RTC_V_FEAT, RTC_V_KOPS, true>), dim3(grid), dim3(RTC_LDS_BLOCK), lds_bytes, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
   else hipLaunchKernelGGL((wf_ts<false, RTC_V_FEAT, RTC_V_KOPS, true>), dim3(grid), dim3(RTC_LDS_BLOCK), lds_bytes, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
+  return true;
 #else
-  RTC_CAT(rtc_launch_wf_ts_v, RTC_VARIANT)(count, grid, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
-  (void)lds_bytes;
+  (void)count; (void)grid; (void)lds_bytes; (void)stream; (void)S; (void)cam; (void)pm; (void)W; (void)tl; (void)sl; (void)n0; (void)slot; (void)fuel_left;
+  (void)hit_t; (void)hit_prim; (void)hit_k; (void)stats;
+  return false;
 #endif
 }
 

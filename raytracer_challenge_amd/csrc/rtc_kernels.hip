@@ -11,7 +11,7 @@
   void rtc_launch_wf_ts_v##N(bool count, unsigned grid, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, const DWave& W, int tl, \
                              int sl, unsigned n0, int slot, int fuel_left, double* hit_t, int* hit_prim, int* hit_k, DStats* stats);                         \
   int rtc_wf_ts_blocks_per_cu_v##N(unsigned lds_bytes);                                                                                                        \
-  void rtc_launch_wf_ts_lds_v##N(bool count, unsigned grid, unsigned lds_bytes, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm,   \
+  bool rtc_launch_wf_ts_lds_v##N(bool count, unsigned grid, unsigned lds_bytes, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm,   \
                                  const DWave& W, int tl, int sl, unsigned n0, int slot, int fuel_left, double* hit_t, int* hit_prim, int* hit_k, DStats* stats);
 RTC_VARIANT_DECL(0) RTC_VARIANT_DECL(1) RTC_VARIANT_DECL(2) RTC_VARIANT_DECL(3) RTC_VARIANT_DECL(4)
 #undef RTC_VARIANT_DECL
@@ -193,18 +193,23 @@ __global__ void __launch_bounds__(256) wf_gather(DCamera cam, DPixelMap pm, DWav
     int wait_idx[RTC_MAX_FUEL + 1];  // refracted children waiting for their turn; entry k belongs to level wait_lvl[k]
     int wait_lvl[RTC_MAX_FUEL + 1];
     int sp = 0, lvl = 0, idx = (int)i;
+    const bool digest = W.dig != nullptr && pm.digest != nullptr;  // parity channel: the same walk sums the rays' hit hashes
+    unsigned long long dg = 0ull;
+    int kind = 0;
     for (;;) {
       const double* cb = W.contrib + (size_t)lvl * 3 * cap;
       const int32_t* ch = W.child + (size_t)lvl * 2 * cap;
       const int a = ch[idx], c = ch[cap + idx];
       if (a != RTC_WF_MISS) { r += cb[idx]; g += cb[cap + idx]; b += cb[2 * cap + idx]; }  // a miss wrote no contribution
+      if (digest) dg += rtc_hit_hash(W.dig[(size_t)lvl * cap + idx], lvl, kind);
       if (c >= 0) { wait_idx[sp] = c; wait_lvl[sp] = lvl + 1; sp++; }
-      if (a >= 0) { idx = a; lvl++; continue; }
+      if (a >= 0) { idx = a; lvl++; kind = 1; continue; }
       if (sp == 0) break;
       sp--;
-      idx = wait_idx[sp]; lvl = wait_lvl[sp];
+      idx = wait_idx[sp]; lvl = wait_lvl[sp]; kind = 2;
     }
     rgb[3 * q + 0] = r; rgb[3 * q + 1] = g; rgb[3 * q + 2] = b;
+    if (digest) pm.digest[q] = dg;
   }
 }
 
@@ -229,10 +234,10 @@ unsigned rtc_wavefront_lds_bytes(const DScene& S) {
   const unsigned long long need = rtc_lds_table_bytes(S) + (unsigned long long)RTC_LDS_BLOCK * (unsigned)S.bvh_stack * sizeof(int);
   return need <= 158ull * 1024 ? (unsigned)need : 0u;
 }
-static void launch_wf_ts_lds(int v, bool count, unsigned grid, unsigned lds, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, const DWave& W, int tl,
+static bool launch_wf_ts_lds(int v, bool count, unsigned grid, unsigned lds, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, const DWave& W, int tl,
                              int sl, unsigned n0, int slot, int fuel_left, double* hit_t, int* hit_prim, int* hit_k, DStats* stats) {
-  if (v == 0) rtc_launch_wf_ts_lds_v0(count, grid, lds, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
-  else rtc_launch_wf_ts_lds_v1(count, grid, lds, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
+  if (v == 0) return rtc_launch_wf_ts_lds_v0(count, grid, lds, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
+  return rtc_launch_wf_ts_lds_v1(count, grid, lds, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
 }
 
 // Grid of the wavefront traversal kernel: as many one-wave blocks as the chip holds at once (the kernel hands out chunks
@@ -274,8 +279,8 @@ void rtc_launch_wavefront(const DScene& S, const DCamera& cam, const DPixelMap& 
   for (int level = 0; level <= fuel + 1; level++) {
     const int tl = level <= fuel ? level : -1, sl = level - 1;
 #ifndef RTC_EMU
-    if (lds) launch_wf_ts_lds(v, count, lds_blocks, lds, stream, S, cam, pm, W, tl, sl, n0, level, fuel - level, hit_t, hit_prim, hit_k, stats);
-    else
+    // (a device that refuses the LDS size — the opt-in is per device — runs the kernel that reads the tables from memory)
+    if (!lds || !launch_wf_ts_lds(v, count, lds_blocks, lds, stream, S, cam, pm, W, tl, sl, n0, level, fuel - level, hit_t, hit_prim, hit_k, stats))
 #endif
     launch_wf_ts(v, count, blocks, stream, S, cam, pm, W, tl, sl, n0, level, fuel - level, hit_t, hit_prim, hit_k, stats);
     if (level <= fuel) {
@@ -299,6 +304,20 @@ __global__ void __launch_bounds__(256) rtc_quantize_kernel(const double* __restr
     out[i] = (unsigned char)(r <= 0.0 ? 0.0 : (r >= 255.0 ? 255.0 : r));
   }
 }
+// The kernels' SoA primary-hit rows -> the C ABI's 16-byte records (include/rtc.h rtc_hit), so that the host copy is one transfer.
+__global__ void __launch_bounds__(256) rtc_pack_hits_kernel(const double* __restrict__ t, const int* __restrict__ prim, const int* __restrict__ k, DHit* __restrict__ out, unsigned long long n) {
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+    DHit h;
+    h.t = t[i]; h.prim = prim[i]; h.k = k[i];
+    out[i] = h;
+  }
+}
+void rtc_launch_pack_hits(const double* t, const int* prim, const int* k, DHit* out, unsigned long long n, hipStream_t stream) {
+  if (n == 0) return;
+  unsigned long long blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(rtc_pack_hits_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t, prim, k, out, n);
+}
 void rtc_launch_quantize(const double* rgb, unsigned char* out, unsigned long long n, hipStream_t stream) {
   if (n == 0) return;
   unsigned long long blocks = (n + 255) / 256;
@@ -308,36 +327,39 @@ void rtc_launch_quantize(const double* rgb, unsigned char* out, unsigned long lo
 
 
 // Multi-GPU gather, last step: image row k + n j  <-  row j of replica k's dense tile in the slab.
+// (bands of `band` rows: image row y is row ((y / band) / n) * band + y % band of replica (y / band) % n's tile)
 __global__ void __launch_bounds__(256) rtc_deinterleave_kernel(const double* __restrict__ slab, double* __restrict__ image, unsigned rowlen, unsigned vsize, unsigned n,
-                                                               unsigned max_rows) {
+                                                               unsigned max_rows, unsigned band) {
   const unsigned long long total = (unsigned long long)vsize * rowlen;
   for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * blockDim.x) {
     const unsigned y = (unsigned)(i / rowlen), x = (unsigned)(i % rowlen);
-    image[i] = slab[((unsigned long long)(y % n) * max_rows + y / n) * rowlen + x];
+    const unsigned b = y / band;
+    image[i] = slab[((unsigned long long)(b % n) * max_rows + (b / n) * band + y % band) * rowlen + x];
   }
 }
 // The same for quantised tiles (rtc_render_multi_rgb8: every replica quantises its own rows, so 3 bytes per pixel cross xGMI, not 24).
 __global__ void __launch_bounds__(256) rtc_deinterleave8_kernel(const unsigned char* __restrict__ slab, unsigned char* __restrict__ image, unsigned rowlen, unsigned vsize,
-                                                                unsigned n, unsigned max_rows) {
+                                                                unsigned n, unsigned max_rows, unsigned band) {
   const unsigned long long total = (unsigned long long)vsize * rowlen;
   for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * blockDim.x) {
     const unsigned y = (unsigned)(i / rowlen), x = (unsigned)(i % rowlen);
-    image[i] = slab[((unsigned long long)(y % n) * max_rows + y / n) * rowlen + x];
+    const unsigned b = y / band;
+    image[i] = slab[((unsigned long long)(b % n) * max_rows + (b / n) * band + y % band) * rowlen + x];
   }
 }
-void rtc_launch_deinterleave8(const unsigned char* slab, unsigned char* image, unsigned rowlen, unsigned vsize, unsigned n, unsigned max_rows, hipStream_t stream) {
+void rtc_launch_deinterleave8(const unsigned char* slab, unsigned char* image, unsigned rowlen, unsigned vsize, unsigned n, unsigned max_rows, unsigned band, hipStream_t stream) {
   const unsigned long long total = (unsigned long long)vsize * rowlen;
   if (total == 0) return;
   unsigned long long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(rtc_deinterleave8_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slab, image, rowlen, vsize, n, max_rows);
+  hipLaunchKernelGGL(rtc_deinterleave8_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slab, image, rowlen, vsize, n, max_rows, band ? band : 1u);
 }
-void rtc_launch_deinterleave(const double* slab, double* image, unsigned rowlen, unsigned vsize, unsigned n, unsigned max_rows, hipStream_t stream) {
+void rtc_launch_deinterleave(const double* slab, double* image, unsigned rowlen, unsigned vsize, unsigned n, unsigned max_rows, unsigned band, hipStream_t stream) {
   const unsigned long long total = (unsigned long long)vsize * rowlen;
   if (total == 0) return;
   unsigned long long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(rtc_deinterleave_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slab, image, rowlen, vsize, n, max_rows);
+  hipLaunchKernelGGL(rtc_deinterleave_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slab, image, rowlen, vsize, n, max_rows, band ? band : 1u);
 }
 
 // One-kernel path: one lane per work id (tile padding included).  big_scene: the accelerator does not fit the L2s.

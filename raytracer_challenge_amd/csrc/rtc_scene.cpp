@@ -4,12 +4,18 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rtc.h"
@@ -19,8 +25,9 @@
 void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
                       DStats* stats, bool count, hipStream_t stream, bool big_scene);
 void rtc_launch_quantize(const double* rgb, unsigned char* out, unsigned long long n, hipStream_t stream);
-void rtc_launch_deinterleave(const double* slab, double* image, unsigned rowlen, unsigned vsize, unsigned n, unsigned max_rows, hipStream_t stream);
-void rtc_launch_deinterleave8(const unsigned char* slab, unsigned char* image, unsigned rowlen, unsigned vsize, unsigned n, unsigned max_rows, hipStream_t stream);
+void rtc_launch_pack_hits(const double* t, const int* prim, const int* k, DHit* out, unsigned long long n, hipStream_t stream);
+void rtc_launch_deinterleave(const double* slab, double* image, unsigned rowlen, unsigned vsize, unsigned n, unsigned max_rows, unsigned band, hipStream_t stream);
+void rtc_launch_deinterleave8(const unsigned char* slab, unsigned char* image, unsigned rowlen, unsigned vsize, unsigned n, unsigned max_rows, unsigned band, hipStream_t stream);
 void rtc_launch_wavefront(const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, const DWave& W, double* rgb, double* hit_t, int* hit_prim, int* hit_k,
                           DStats* stats, bool count, hipStream_t stream, unsigned blocks, unsigned shade_blocks);
 uint64_t rtc_wavefront_work(const DCamera& cam, const DPixelMap& pm);
@@ -54,6 +61,12 @@ struct rtc_scene {
   double* d_hit_t = nullptr;
   int* d_hit_prim = nullptr;
   int* d_hit_k = nullptr;
+  DHit* d_hits = nullptr;   // packed {t, prim, push} records for the copy to the host (rtc_hit layout)
+  unsigned long long* d_digest = nullptr;    // hit-tree digests of a parity launch (per output slot)
+  unsigned long long* d_wave_dig = nullptr;  //   and, wavefront path, the per-level hit hashes they are summed from
+  uint64_t cap_digest = 0, cap_wave_dig = 0;
+  uint8_t* d_rgb8 = nullptr;
+  uint64_t cap_hits = 0, cap_rgb8 = 0;
   uint64_t* d_idx = nullptr;
   double* d_rays = nullptr;
   uint64_t cap_px = 0, cap_idx = 0, cap_rays = 0;
@@ -62,6 +75,12 @@ struct rtc_scene {
   double tune_ms[2] = {-1.0, -1.0};
   int tune_n[2] = {0, 0};
   int tune_choice = 0;
+  // what the scene is made of, for the first-launch path guess (pick_path)
+  uint32_t n_analytic = 0;      // bounded analytic primitives (the world BVH's leaves)
+  uint32_t n_bouncing = 0;      // primitives whose material reflects or refracts
+  uint32_t n_prims_total = 0;
+  bool last_wavefront = false;  // path of the most recent launch (for stats read back after an asynchronous launch)
+  int last_fuel = 0;
   DCsgHit* csg_slab = nullptr;  // CSG subtrees beyond the per-lane buffer: csg_max_hits rows per thread of the largest launch so far
   uint64_t csg_slab_threads = 0;
   bool wave_alloc_failed = false;  // the device refused the queues once: launches stay on the one-kernel path
@@ -102,8 +121,37 @@ int ensure_px(rtc_scene* s, uint64_t n, bool hits) {
     HIP_OK(hipMalloc((void**)&s->d_hit_k, n * sizeof(int)));
     s->cap_px = n;
   }
-  (void)hits;
+  if (hits && n > s->cap_hits) {
+    (void)hipFree(s->d_hits);
+    s->d_hits = nullptr; s->cap_hits = 0;
+    HIP_OK(hipMalloc((void**)&s->d_hits, n * sizeof(DHit)));
+    s->cap_hits = n;
+  }
   return RTC_OK;
+}
+
+// ---- device -> host for the caller's output buffers (Image::par_render returns host pixels, src/image.rs:76-80) ----------------
+// Measured on the GPU box (scripts/d2h_probe.hip, profiles/r3_d2h_probe.txt): a pageable hipMemcpy runs at PCIe speed (52-56 GB/s)
+// once the destination's pages exist; what made round 2's rtc_render 13x slower than its kernels was the destination itself —
+// a freshly allocated buffer (Vec / calloc / numpy.empty) has no pages yet and they were faulted in one by one inside the copy —
+// plus three temporary vectors and a scalar host loop for the hit records.  So: (1) while the device renders, a few host threads
+// touch the destination's pages (each page's first byte is written back to itself: contents unchanged, page present);
+// (2) hit records are packed on the device into the caller's layout; (3) one copy per output array, straight into the caller's
+// memory, queued on the scene's stream behind the kernels.
+void pretouch_pages(void* p, size_t bytes, std::vector<std::thread>* pool) {
+  if (!p || bytes < (4u << 20)) return;
+  static const int T = [] { const char* e = std::getenv("RTC_PRETOUCH_THREADS"); int t = e ? std::atoi(e) : 8; return t < 0 ? 0 : (t > 32 ? 32 : t); }();
+  if (T == 0) return;
+  char* base = (char*)p;
+  const size_t per = ((bytes / (size_t)T) + 4095) & ~(size_t)4095;
+  for (int t = 0; t < T; t++) {
+    const size_t b = std::min(bytes, per * (size_t)t), e = std::min(bytes, per * (size_t)(t + 1));
+    if (e > b) pool->emplace_back([base, b, e] { for (size_t o = b; o < e; o += 4096) { volatile char* q = base + o; *q = *q; } });
+  }
+}
+void join_all(std::vector<std::thread>* pool) {
+  for (auto& t : *pool) t.join();
+  pool->clear();
 }
 
 // Sizes the wavefront arrays for `n_work` level-0 work ids and fuel + 1 levels: every level may hold up to wave_eighths / 8 x
@@ -156,24 +204,37 @@ uint64_t launch_signature(const DCamera& cam, const DPixelMap& pm, int fuel) {
   uint64_t h = 1469598103934665603ull;
   auto mix = [&](const void* p, size_t n) { for (size_t i = 0; i < n; i++) { h ^= ((const unsigned char*)p)[i]; h *= 1099511628211ull; } };
   mix(&cam, sizeof(cam));
-  mix(&pm.n, sizeof(pm.n)); mix(&pm.mode, sizeof(pm.mode)); mix(&pm.row_first, sizeof(pm.row_first)); mix(&pm.row_step, sizeof(pm.row_step));
+  mix(&pm.n, sizeof(pm.n)); mix(&pm.mode, sizeof(pm.mode)); mix(&pm.row_first, sizeof(pm.row_first)); mix(&pm.row_step, sizeof(pm.row_step)); mix(&pm.band, sizeof(pm.band));
   mix(&fuel, sizeof(fuel));
   return h ? h : 1;
 }
 
-// Which path renders a launch (RTC_KERNEL unset).  The one-kernel path wins on cheap frames (few bounces, ~1 ms), the
-// wavefront path on deep ray trees (config 2: 1.6x); which one depends on scene, camera and fuel, so the choice is
-// measured: for a given launch signature the first four synchronous launches alternate between the paths (the smaller of a
-// path's two times counts) and every later launch (synchronous or not) takes the faster.  Until then: a guess from the materials and the launch size.  A wavefront launch
-// whose queues overflowed is rendered again by the one-kernel path and never chosen for that signature, so an
-// unsynchronised wavefront launch only ever repeats a launch that is known to fit.
-int pick_path(rtc_scene* s, uint64_t sig, uint64_t n_work, bool will_sync, bool pixel_list) {
+// Which path renders a launch (RTC_KERNEL unset).  The one-kernel path wins where rays are cheap (planes + one gated mesh:
+// the teapot scenes, 0.85 vs 1.5 ms), the wavefront path where a ray walks a BVH of analytic primitives and the ray trees
+// are deep (config 2: 2.3 vs 4.2 ms); which one depends on scene, camera and fuel, so the choice is measured where it can be:
+// for a given launch signature the first four SYNCHRONOUS launches alternate between the paths, starting with the guess below (the
+// smaller of a path's two times counts), and every later launch — synchronous or not — takes the faster.  Until a signature is
+// measured, and for a caller that renders one frame per scene (the reference's only call pattern, src/bin/*.rs), the guess decides:
+// first_guess() — wavefront iff the scene has an analytic BVH worth walking (>= 32 bounded analytic primitives), a tenth of its
+// primitives reflect or refract, the frame is large enough to fill per-level launches and fuel allows bounces; else one kernel,
+// which also never allocates ray queues.  (Calibrated on the nine reference scenes and the five BASELINE configs:
+// profiles/r3_path_choice.txt.)  A wavefront launch whose queues overflowed is rendered again by the one-kernel path and never chosen for
+// that signature, so an unsynchronised wavefront launch only ever repeats a launch that is known to fit.
+int first_guess(const rtc_scene* s, uint64_t n_work, int fuel) {
+  if (const char* e = std::getenv("RTC_FIRST_GUESS")) { const int v = std::atoi(e); if (v == 1 || v == 4) return v; }
+  const bool deep = fuel >= 2 && (uint64_t)s->n_bouncing * 10u >= (uint64_t)s->n_prims_total && s->n_bouncing > 0;
+  return (s->n_analytic >= 32 && deep && n_work >= (256u << 10)) ? 4 : 1;
+}
+int pick_path(rtc_scene* s, uint64_t sig, uint64_t n_work, int fuel, bool will_sync, bool pixel_list) {
   if (sig != s->tune_sig) { s->tune_sig = sig; s->tune_ms[0] = s->tune_ms[1] = -1.0; s->tune_n[0] = s->tune_n[1] = 0; s->tune_choice = 0; }
   if (pixel_list) return 1;  // index lists and explicit rays: small, irregular launches
   if (s->tune_choice) return s->tune_choice;
+  const int guess = first_guess(s, n_work, fuel);
+  if (!will_sync) return guess;
   // two samples per path, alternating, the smaller one counts: a path's first launch pays for code loading and scratch
-  if (will_sync) return s->tune_n[1] <= s->tune_n[0] ? 4 : 1;
-  return 1;
+  const int other = guess == 4 ? 1 : 4;
+  const int ng = s->tune_n[guess == 4 ? 1 : 0], no = s->tune_n[other == 4 ? 1 : 0];
+  return ng <= no ? guess : other;
 }
 
 // Sticky error state of the scene (DStats tail): read and cleared together.
@@ -184,7 +245,27 @@ int read_clear_sticky(rtc_scene* s, DStats* h) {
   return RTC_OK;
 }
 
-int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb, bool want_hits, rtc_stats* stats, bool count, bool sync, int force = 0) {
+// rtc_stats of the scene's most recent launch from its device counters `h` (read after the stream went idle).
+int fill_stats(rtc_scene* s, const DStats& h, uint64_t pixels, rtc_stats* stats) {
+  float ms = 0.f;
+  HIP_OK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+  std::memset(stats, 0, sizeof(*stats));
+  stats->pixels = pixels;
+  stats->rays_primary = h.rays_primary; stats->rays_shadow = h.rays_shadow; stats->rays_reflect = h.rays_reflect; stats->rays_refract = h.rays_refract;
+  stats->rays_container = h.rays_container; stats->accel_nodes = h.accel_nodes; stats->group_tests = h.group_tests; stats->tri_tests = h.tri_tests;
+  stats->analytic_tests = h.analytic_tests; stats->nan_ts = h.nan_ts;
+  stats->accel_nodes_kernarg = h.knodes; stats->analytic_tests_kernarg = h.kplanes; stats->light_grid_cells = h.light_cells;
+  stats->group_tests_uniform = h.kgroups;
+  stats->kernel_ms = ms;
+  stats->n_launches = s->last_wavefront ? 2u * (uint32_t)s->last_fuel + 4u : 1u;
+  return RTC_OK;
+}
+
+// `after` (optional): queued behind the kernels of EVERY attempt of this launch, before the host waits (the copies of a host-pixel
+// render); a launch that is rendered again (queue overflow -> larger queues / the other path) calls it again.
+typedef std::function<int()> AfterLaunch;
+int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb, bool want_hits, rtc_stats* stats, bool count, bool sync, int force = 0,
+        const AfterLaunch* after = nullptr) {
   if (fuel < 0) fuel = 0;  // fuel <= 0 spawns nothing (src/world.rs:90,110)
   if (fuel > RTC_MAX_FUEL) return rtc_fail(RTC_ERR_INVALID, "fuel exceeds RTC_MAX_FUEL");
   HIP_OK(hipSetDevice(s->device));
@@ -194,7 +275,7 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
   const bool will_sync = sync || stats != nullptr;
   const bool tuned = force == 0 && s->kernel_version == 0;
   int path = force ? force : s->kernel_version;
-  if (tuned) path = pick_path(s, launch_signature(cam, pm, fuel), rtc_wavefront_work(cam, pm), will_sync, pm.mode != 2);
+  if (tuned) path = pick_path(s, launch_signature(cam, pm, fuel), rtc_wavefront_work(cam, pm), fuel, will_sync, pm.mode != 2);
   if (path == 4 && s->wave_alloc_failed && force == 0) path = 1;
   const bool wavefront = path == 4 && pm.n > 0;
   if (s->d.csg_max_hits > RTC_CSG_MAX_HITS) {
@@ -219,9 +300,21 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
       // does not fit the memory budget / the device's free memory: this launch shape stays on the one-kernel path (same bits)
       if (tuned) { s->tune_ms[1] = 1e30; s->tune_n[1] = 2; s->tune_choice = 1; }
       else s->wave_alloc_failed = true;
-      return run(s, cam, pm, fuel, d_rgb, want_hits, stats, count, sync, 1);
+      return run(s, cam, pm, fuel, d_rgb, want_hits, stats, count, sync, 1, after);
     }
     if (rc != RTC_OK) return rc;
+    s->wave.dig = nullptr;
+    if (pm.digest && count) {  // parity launch: (levels) x cap hit hashes beside the queues
+      const uint64_t need = (uint64_t)s->wave_cap * (uint64_t)(fuel + 1);
+      if (need > s->cap_wave_dig) {
+        HIP_OK(hipStreamSynchronize(s->stream));
+        (void)hipFree(s->d_wave_dig);
+        s->d_wave_dig = nullptr; s->cap_wave_dig = 0;
+        HIP_OK(hipMalloc((void**)&s->d_wave_dig, need * sizeof(unsigned long long)));
+        s->cap_wave_dig = need;
+      }
+      s->wave.dig = s->d_wave_dig;
+    }
     HIP_OK(hipMemsetAsync(s->wave.counts, 0, RTC_WF_COUNTS * sizeof(uint32_t), s->stream));
     HIP_OK(hipEventRecord(s->ev0, s->stream));
     rtc_launch_wavefront(s->d, cam, pm, fuel, s->wave, d_rgb, want_hits ? s->d_hit_t : nullptr, s->d_hit_prim, s->d_hit_k, s->d_stats, count, s->stream, s->wave_blocks, s->shade_blocks);
@@ -230,6 +323,9 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
   }
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(s->ev1, s->stream));
+  s->last_wavefront = wavefront;
+  s->last_fuel = fuel;
+  if (after) { int rca = (*after)(); if (rca != RTC_OK) return rca; }
   if (!sync && !stats) return RTC_OK;
   HIP_OK(hipStreamSynchronize(s->stream));
   DStats h;
@@ -249,11 +345,11 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
       const uint64_t n_work = rtc_wavefront_work(cam, pm);
       if (s->wave_eighths < 512 && wave_bytes(wave_cap(s, n_work, 2 * s->wave_eighths), fuel + 1) <= wave_budget() && wave_cap(s, n_work, 2 * s->wave_eighths) <= 0x7fffff00ull) {
         s->wave_eighths *= 2;
-        const int rc2 = run(s, cam, pm, fuel, d_rgb, want_hits, stats, count, true, 4);
+        const int rc2 = run(s, cam, pm, fuel, d_rgb, want_hits, stats, count, true, 4, after);
         if (rc2 != RTC_ERR_UNSUPPORTED) return rc2;  // (the larger queues were refused by the device: fall through)
       }
       if (tuned) { s->tune_ms[1] = 1e30; s->tune_n[1] = 2; s->tune_choice = 1; }
-      return run(s, cam, pm, fuel, d_rgb, want_hits, stats, count, true, 1);
+      return run(s, cam, pm, fuel, d_rgb, want_hits, stats, count, true, 1, after);
     }
   }
   if (tuned && !count && pm.mode == 2 && !s->tune_choice) {
@@ -265,16 +361,8 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
     if (s->tune_n[0] >= 2 && s->tune_n[1] >= 2) s->tune_choice = s->tune_ms[1] < s->tune_ms[0] ? 4 : 1;
   }
   if (stats) {
-    float ms = 0.f;
-    HIP_OK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
-    std::memset(stats, 0, sizeof(*stats));
-    stats->pixels = pm.n;
-    stats->rays_primary = h.rays_primary; stats->rays_shadow = h.rays_shadow; stats->rays_reflect = h.rays_reflect; stats->rays_refract = h.rays_refract;
-    stats->rays_container = h.rays_container; stats->accel_nodes = h.accel_nodes; stats->group_tests = h.group_tests; stats->tri_tests = h.tri_tests;
-    stats->analytic_tests = h.analytic_tests; stats->nan_ts = h.nan_ts;
-    stats->accel_nodes_kernarg = h.knodes; stats->analytic_tests_kernarg = h.kplanes; stats->light_grid_cells = h.light_cells;
-    stats->kernel_ms = ms;
-    stats->n_launches = wavefront ? 2u * (uint32_t)fuel + 4u : 1u;
+    int rcf = fill_stats(s, h, pm.n, stats);
+    if (rcf != RTC_OK) return rcf;
   }
   if (std::getenv("RTC_DIAG_DUMP")) {  // RTC_DIAG builds: raw region / utilisation counters for scripts/diag_report.py
     std::fprintf(stderr, "[rtc-diag]");
@@ -284,6 +372,67 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
   if (h.guard) return rtc_fail(RTC_ERR_DEVICE, "traversal guard tripped (mask " + std::to_string(h.guard) + "): an index left its array; no pixel since the last check is trustworthy");
   if (h.nan_ts) return rtc_fail(RTC_ERR_NAN, "a NaN intersection t was produced (the reference panics in Intersection::sort, src/intersection.rs:124)");
   return RTC_OK;
+}
+
+// The pixel map of a host-side launch over pixels first .. first + n - 1 or the n listed indices (uploaded to the scene's index buffer).
+int make_pixel_map(rtc_scene* s, const rtc_camera* cam, const uint64_t* pixel_indices, uint64_t first, uint64_t n, DPixelMap* pm, std::vector<uint64_t>* range_idx) {
+  const uint64_t total = cam->hsize * cam->vsize;
+  *pm = DPixelMap{};
+  pm->n = n;
+  // A contiguous range is expressed through the two pixel maps the kernels are validated with on hardware: whole rows ->
+  // interleaved-row map with step 1; anything else -> an explicit index list.
+  if (!pixel_indices) {
+    if (first % cam->hsize == 0 && n % cam->hsize == 0) {
+      pm->mode = 2; pm->row_first = (uint32_t)(first / cam->hsize); pm->row_step = 1;
+    } else {
+      range_idx->resize(n);
+      for (uint64_t i = 0; i < n; i++) (*range_idx)[i] = first + i;
+      pixel_indices = range_idx->data();
+    }
+  }
+  if (pixel_indices) {
+    for (uint64_t i = 0; i < n; i++)
+      if (pixel_indices[i] >= total) return rtc_fail(RTC_ERR_INVALID, "pixel index exceeds the image");
+    if (n > s->cap_idx) {
+      if (s->d_idx) (void)hipFree(s->d_idx);
+      s->d_idx = nullptr; s->cap_idx = 0;
+      HIP_OK(hipMalloc((void**)&s->d_idx, n * sizeof(uint64_t)));
+      s->cap_idx = n;
+    }
+    HIP_OK(hipMemcpy(s->d_idx, pixel_indices, n * sizeof(uint64_t), hipMemcpyHostToDevice));
+    pm->mode = 1; pm->indices = s->d_idx;
+  }
+  return RTC_OK;
+}
+
+// One launch whose results go to the caller's host buffers: rgb (n x 3 doubles) or rgb8 (n x 3 bytes, Color::clamp on the device),
+// and optionally the primary-hit records.  The destination's pages are touched by host threads while the device renders, the
+// copies are queued behind the kernels (see pretouch_pages above).
+int render_to_host(rtc_scene* s, const DCamera& dc, const DPixelMap& pm, int fuel, double* rgb, uint8_t* rgb8, rtc_hit* hits, rtc_stats* stats) {
+  static_assert(sizeof(DHit) == sizeof(rtc_hit) && offsetof(DHit, prim) == offsetof(rtc_hit, prim) && offsetof(DHit, k) == offsetof(rtc_hit, push_idx), "hit layout");
+  const uint64_t n = pm.n;
+  std::vector<std::thread> pool;
+  bool touched = false;
+  const AfterLaunch after = [&]() -> int {
+    if (!touched) {  // (a launch that is rendered again finds the pages present)
+      touched = true;
+      if (rgb) pretouch_pages(rgb, n * 3 * sizeof(double), &pool);
+      if (rgb8) pretouch_pages(rgb8, n * 3, &pool);
+      if (hits) pretouch_pages(hits, n * sizeof(rtc_hit), &pool);
+    }
+    if (rgb8) rtc_launch_quantize(s->d_rgb, s->d_rgb8, n * 3, s->stream);
+    if (hits) rtc_launch_pack_hits(s->d_hit_t, s->d_hit_prim, s->d_hit_k, s->d_hits, n, s->stream);
+    hipError_t e = hipGetLastError();
+    join_all(&pool);
+    if (e == hipSuccess && rgb) e = hipMemcpyAsync(rgb, s->d_rgb, n * 3 * sizeof(double), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess && rgb8) e = hipMemcpyAsync(rgb8, s->d_rgb8, n * 3, hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess && hits) e = hipMemcpyAsync(hits, s->d_hits, n * sizeof(rtc_hit), hipMemcpyDeviceToHost, s->stream);
+    if (e != hipSuccess) return rtc_fail(RTC_ERR_DEVICE, std::string("copy to the host: ") + hipGetErrorString(e));
+    return RTC_OK;
+  };
+  const int rc = run(s, dc, pm, fuel, s->d_rgb, hits != nullptr, stats, stats != nullptr, true, 0, &after);
+  join_all(&pool);  // (an error before the hook ran its join)
+  return rc;
 }
 
 }  // namespace
@@ -314,7 +463,9 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
   int rc = rtb::build_arrays(*desc, &H, &err, device_bvh ? rtc_bvh_build_device : nullptr);
   if (rc != RTC_OK) return rtc_fail(rc, err);
 
-  std::unique_ptr<rtc_scene> s(new rtc_scene());
+  // (every early return below releases what was created so far: streams, events, uploaded tables)
+  struct SceneDeleter { void operator()(rtc_scene* p) const { rtc_scene_destroy(p); } };
+  std::unique_ptr<rtc_scene, SceneDeleter> s(new rtc_scene());
   s->device = device;
   HIP_OK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   HIP_OK(hipEventCreate(&s->ev0));
@@ -325,11 +476,11 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
 #define UP(field)                                                       \
   do {                                                                  \
     int rc_ = s->upload(H.field, &d.field);                             \
-    if (rc_ != RTC_OK) { rtc_scene_destroy(s.release()); return rc_; } \
+    if (rc_ != RTC_OK) return rc_;                                      \
   } while (0)
   UP(ops); UP(group_box); UP(group_parent); UP(bvh); UP(mtri); UP(mtri_prim); {
     int rc_ = s->upload(H.items, &d.item_prim);
-    if (rc_ != RTC_OK) { rtc_scene_destroy(s.release()); return rc_; }
+    if (rc_ != RTC_OK) return rc_;
     d.quirk_prim = d.item_prim;
     d.qitem = d.item_prim;
   }
@@ -360,6 +511,15 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     d.kqgrid = hv.kqgrid;
     d.n_bvh = hv.n_bvh; d.n_items = hv.n_items; d.n_mtri = hv.n_mtri; d.n_quirk = hv.n_quirk;
     d.n_qitem = hv.n_qitem; d.n_qcell = hv.n_qcell; d.n_groups = hv.n_groups; d.n_qgrids = hv.n_qgrids;
+  }
+  s->n_prims_total = desc->n_prims;
+  for (uint32_t i = 0; i < desc->n_prims; i++) {
+    const rtc_prim& P = desc->prims[i];
+    if (P.geometry != RTC_PLANE && P.geometry != RTC_TRIANGLE && P.geometry != RTC_SMOOTH_TRIANGLE) s->n_analytic++;
+    if (P.material >= 0 && (uint32_t)P.material < desc->n_materials) {
+      const rtc_material& M = desc->materials[P.material];
+      if (M.reflective != 0.0 || M.transparency != 0.0) s->n_bouncing++;
+    }
   }
   s->bvh_depth = H.bvh_depth;
   s->built_on_device = H.built_on_device;
@@ -407,6 +567,7 @@ void rtc_scene_destroy(rtc_scene* s) {
   for (void* p : s->allocs) (void)hipFree(p);
   if (s->d_stats) (void)hipFree(s->d_stats);
   (void)hipFree(s->d_rgb); (void)hipFree(s->d_hit_t); (void)hipFree(s->d_hit_prim); (void)hipFree(s->d_hit_k);
+  (void)hipFree(s->d_hits); (void)hipFree(s->d_rgb8); (void)hipFree(s->d_digest); (void)hipFree(s->d_wave_dig);
   if (s->wave_mem) (void)hipFree(s->wave_mem);
   (void)hipFree(s->csg_slab);
   if (s->d_idx) (void)hipFree(s->d_idx);
@@ -430,60 +591,103 @@ int rtc_render(rtc_scene* s, const rtc_camera* cam, int32_t fuel, const uint64_t
   HIP_OK(hipSetDevice(s->device));
   int rc = ensure_px(s, n, hits != nullptr);
   if (rc != RTC_OK) return rc;
-  // A contiguous range is expressed through the two pixel maps the kernels are validated with on hardware: whole rows ->
-  // interleaved-row map with step 1; anything else -> an explicit index list.
+  DPixelMap pm{};
+  std::vector<uint64_t> range_idx;
+  rc = make_pixel_map(s, cam, pixel_indices, first, n, &pm, &range_idx);
+  if (rc != RTC_OK) return rc;
+  DCamera dc;
+  to_dcam(*cam, &dc);
+  return render_to_host(s, dc, pm, fuel, rgb, nullptr, hits, stats);
+}
+
+int rtc_render_hit_digest(rtc_scene* s, const rtc_camera* cam, int32_t fuel, const uint64_t* pixel_indices, uint64_t first, uint64_t n, uint64_t* digest) {
+  if (!s || !cam || (!digest && n)) return rtc_fail(RTC_ERR_INVALID, "NULL argument");
+  if (cam->hsize == 0 || cam->vsize == 0) return rtc_fail(RTC_ERR_INVALID, "empty camera");
+  const uint64_t total = cam->hsize * cam->vsize;
+  if (!pixel_indices && first + n > total) return rtc_fail(RTC_ERR_INVALID, "pixel range exceeds the image");
+  if (n == 0) return RTC_OK;
+  HIP_OK(hipSetDevice(s->device));
+  int rc = ensure_px(s, n, false);
+  if (rc != RTC_OK) return rc;
+  if (n > s->cap_digest) {
+    (void)hipFree(s->d_digest);
+    s->d_digest = nullptr; s->cap_digest = 0;
+    HIP_OK(hipMalloc((void**)&s->d_digest, n * sizeof(unsigned long long)));
+    s->cap_digest = n;
+  }
   DPixelMap pm{};
   pm.n = n;
   std::vector<uint64_t> range_idx;
-  if (!pixel_indices) {
-    if (first % cam->hsize == 0 && n % cam->hsize == 0) {
-      pm.mode = 2; pm.row_first = (uint32_t)(first / cam->hsize); pm.row_step = 1;
-    } else {
-      range_idx.resize(n);
-      for (uint64_t i = 0; i < n; i++) range_idx[i] = first + i;
-      pixel_indices = range_idx.data();
-    }
-  }
-  if (pixel_indices) {
-    for (uint64_t i = 0; i < n; i++)
-      if (pixel_indices[i] >= total) return rtc_fail(RTC_ERR_INVALID, "pixel index exceeds the image");
-    if (n > s->cap_idx) {
-      if (s->d_idx) (void)hipFree(s->d_idx);
-      s->d_idx = nullptr; s->cap_idx = 0;
-      HIP_OK(hipMalloc((void**)&s->d_idx, n * sizeof(uint64_t)));
-      s->cap_idx = n;
-    }
-    HIP_OK(hipMemcpy(s->d_idx, pixel_indices, n * sizeof(uint64_t), hipMemcpyHostToDevice));
-    pm.mode = 1; pm.indices = s->d_idx;
-  }
+  rc = make_pixel_map(s, cam, pixel_indices, first, n, &pm, &range_idx);
+  if (rc != RTC_OK) return rc;
+  pm.digest = s->d_digest;
   DCamera dc;
   to_dcam(*cam, &dc);
-  rc = run(s, dc, pm, fuel, s->d_rgb, hits != nullptr, stats, stats != nullptr, true);
+  rtc_stats st;
+  rc = run(s, dc, pm, fuel, s->d_rgb, false, &st, true, true);   // the counting variants carry the digest code
   if (rc != RTC_OK) return rc;
-  HIP_OK(hipMemcpy(rgb, s->d_rgb, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
-  if (hits) {
-    std::vector<double> t(n);
-    std::vector<int> p(n), k(n);
-    HIP_OK(hipMemcpy(t.data(), s->d_hit_t, n * sizeof(double), hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(p.data(), s->d_hit_prim, n * sizeof(int), hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(k.data(), s->d_hit_k, n * sizeof(int), hipMemcpyDeviceToHost));
-    for (uint64_t i = 0; i < n; i++) hits[i] = {t[i], p[i], k[i]};
-  }
+  HIP_OK(hipMemcpy(digest, s->d_digest, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return RTC_OK;
 }
 
-int rtc_render_rows_device(rtc_scene* s, const rtc_camera* cam, int32_t fuel, uint32_t row_first, uint32_t row_step, uint32_t n_rows, double* rgb_dev,
-                           rtc_stats* stats, int count_stats, int sync) {
+int rtc_render_rgb8(rtc_scene* s, const rtc_camera* cam, int32_t fuel, uint8_t* rgb8, rtc_stats* stats) {
+  if (!s || !cam || !rgb8) return rtc_fail(RTC_ERR_INVALID, "NULL argument");
+  if (cam->hsize == 0 || cam->vsize == 0) return rtc_fail(RTC_ERR_INVALID, "empty camera");
+  HIP_OK(hipSetDevice(s->device));
+  const uint64_t n = cam->hsize * cam->vsize;
+  int rc = ensure_px(s, n, false);
+  if (rc != RTC_OK) return rc;
+  if (3 * n > s->cap_rgb8) {
+    (void)hipFree(s->d_rgb8);
+    s->d_rgb8 = nullptr; s->cap_rgb8 = 0;
+    HIP_OK(hipMalloc((void**)&s->d_rgb8, 3 * n));
+    s->cap_rgb8 = 3 * n;
+  }
+  DPixelMap pm{};
+  pm.n = n; pm.mode = 2; pm.row_first = 0; pm.row_step = 1;
+  DCamera dc;
+  to_dcam(*cam, &dc);
+  return render_to_host(s, dc, pm, fuel, nullptr, rgb8, nullptr, stats);
+}
+
+// Rows of the image owned by part `first` of `step` when bands of `band` rows are dealt out round-robin (the last band of the image
+// may be short).
+static uint64_t band_rows_owned(uint64_t vsize, uint32_t band, uint32_t first, uint32_t step) {
+  const uint64_t n_bands = (vsize + band - 1) / band;
+  if (first >= n_bands) return 0;
+  const uint64_t mine = (n_bands - first + step - 1) / step;
+  uint64_t rows = mine * band;
+  const uint64_t last = first + (mine - 1) * (uint64_t)step;  // my last band; short only if it is the image's last
+  if (last == n_bands - 1) rows -= n_bands * band - vsize;
+  return rows;
+}
+
+int rtc_render_bands_device(rtc_scene* s, const rtc_camera* cam, int32_t fuel, uint32_t band_rows, uint32_t band_first, uint32_t band_step, uint32_t n_rows,
+                            double* rgb_dev, rtc_stats* stats, int count_stats, int sync) {
   if (!s || !cam || (!rgb_dev && n_rows)) return rtc_fail(RTC_ERR_INVALID, "NULL argument");
-  if (row_step == 0) return rtc_fail(RTC_ERR_INVALID, "row_step must be >= 1");
-  if (n_rows && (uint64_t)row_first + (uint64_t)(n_rows - 1) * row_step >= cam->vsize) return rtc_fail(RTC_ERR_INVALID, "rows exceed the image");
+  if (band_step == 0 || band_rows == 0) return rtc_fail(RTC_ERR_INVALID, "band_rows and band_step must be >= 1");
+  if (n_rows) {
+    // the launch covers the first n_rows rows of this part's dense tile: whole bands, then possibly part of one
+    const uint64_t j = n_rows - 1, last_row = ((uint64_t)band_first + (j / band_rows) * band_step) * band_rows + j % band_rows;
+    if (last_row >= cam->vsize) return rtc_fail(RTC_ERR_INVALID, "rows exceed the image");
+  }
   DPixelMap pm{};
   pm.n = (uint64_t)n_rows * cam->hsize;
-  pm.mode = 2; pm.row_first = row_first; pm.row_step = row_step;
+  pm.mode = 2; pm.row_first = band_first; pm.row_step = band_step; pm.band = band_rows;
   if (pm.n == 0) { if (stats) std::memset(stats, 0, sizeof(*stats)); return RTC_OK; }
   DCamera dc;
   to_dcam(*cam, &dc);
   return run(s, dc, pm, fuel, rgb_dev, false, stats, count_stats != 0, sync != 0);
+}
+
+int rtc_render_rows_device(rtc_scene* s, const rtc_camera* cam, int32_t fuel, uint32_t row_first, uint32_t row_step, uint32_t n_rows, double* rgb_dev,
+                           rtc_stats* stats, int count_stats, int sync) {
+  return rtc_render_bands_device(s, cam, fuel, 1, row_first, row_step, n_rows, rgb_dev, stats, count_stats, sync);
+}
+
+uint64_t rtc_band_rows_owned(uint64_t vsize, uint32_t band_rows, uint32_t band_first, uint32_t band_step) {
+  if (band_rows == 0 || band_step == 0) return 0;
+  return band_rows_owned(vsize, band_rows, band_first, band_step);
 }
 
 int rtc_trace_rays(rtc_scene* s, const double* rays, uint64_t n, int32_t fuel, double* rgb, rtc_hit* hits, rtc_stats* stats) {
@@ -503,18 +707,7 @@ int rtc_trace_rays(rtc_scene* s, const double* rays, uint64_t n, int32_t fuel, d
   pm.n = n; pm.mode = 3; pm.rays = s->d_rays;
   DCamera dc{};
   dc.hsize = 1; dc.vsize = 1;
-  rc = run(s, dc, pm, fuel, s->d_rgb, hits != nullptr, stats, stats != nullptr, true);
-  if (rc != RTC_OK) return rc;
-  HIP_OK(hipMemcpy(rgb, s->d_rgb, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
-  if (hits) {
-    std::vector<double> t(n);
-    std::vector<int> p(n), k(n);
-    HIP_OK(hipMemcpy(t.data(), s->d_hit_t, n * sizeof(double), hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(p.data(), s->d_hit_prim, n * sizeof(int), hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(k.data(), s->d_hit_k, n * sizeof(int), hipMemcpyDeviceToHost));
-    for (uint64_t i = 0; i < n; i++) hits[i] = {t[i], p[i], k[i]};
-  }
-  return RTC_OK;
+  return render_to_host(s, dc, pm, fuel, rgb, nullptr, hits, stats);
 }
 
 
@@ -645,21 +838,11 @@ struct rtc_multi {
   uint8_t* slab8 = nullptr;
   uint8_t* image8 = nullptr;
   uint64_t slab8_cap = 0, image8_cap = 0;
+  uint32_t band = 8;                // rows per band of the partition (rtc_multi_set_band_rows)
 };
 
 namespace {
 int multi_fail(rtc_multi* m, int rc) { (void)m; return rc; }
-
-// Lets replica s decide its device path for this launch shape (the measured choice needs synchronous launches).
-int ensure_tuned(rtc_scene* s, const DCamera& dc, const DPixelMap& pm, int fuel, double* d_rgb) {
-  if (s->kernel_version != 0) return RTC_OK;
-  for (int i = 0; i < 4; i++) {
-    if (s->tune_choice != 0 && s->tune_sig == launch_signature(dc, pm, fuel)) break;
-    int rc = run(s, dc, pm, fuel, d_rgb, false, nullptr, false, true);
-    if (rc != RTC_OK) return rc;
-  }
-  return RTC_OK;
-}
 
 int render_multi(rtc_multi* m, const rtc_camera* cam, int32_t fuel, double* rgb_dev_out, double* rgb_host, rtc_stats* stats, bool sync, uint8_t* rgb8_host = nullptr) {
   const bool q8 = rgb8_host != nullptr;
@@ -668,7 +851,8 @@ int render_multi(rtc_multi* m, const rtc_camera* cam, int32_t fuel, double* rgb_
   const uint32_t n = (uint32_t)m->scenes.size();
   const uint64_t H = cam->hsize, V = cam->vsize, rowlen = H * 3;
   if (rowlen > 0xffffffffull || V > 0xffffffffull) return rtc_fail(RTC_ERR_INVALID, "image too large");
-  const uint64_t max_rows = (V + n - 1) / n;
+  const uint32_t B = m->band;
+  const uint64_t max_rows = (((V + B - 1) / B + n - 1) / n) * B;
   rtc_scene* s0 = m->scenes[0];
   DCamera dc;
   to_dcam(*cam, &dc);
@@ -729,26 +913,16 @@ int render_multi(rtc_multi* m, const rtc_camera* cam, int32_t fuel, double* rgb_
   for (uint32_t k = 0; k < n; k++) {
     rtc_scene* s = m->scenes[k];
     DPixelMap pm{};
-    const uint64_t rows = k < V ? (V - k + n - 1) / n : 0;
-    pm.n = rows * H; pm.mode = 2; pm.row_first = k; pm.row_step = n;
+    const uint64_t rows = band_rows_owned(V, B, k, n);
+    pm.n = rows * H; pm.mode = 2; pm.row_first = k; pm.row_step = n; pm.band = B;
     if (pm.n == 0) continue;
     if (m->copied_valid[k]) {  // frames queued back to back: the previous frame's gather still reads this tile
       HIP_OK(hipSetDevice(s->device));
       HIP_OK(hipStreamWaitEvent(s->stream, m->copied[k], 0));
     }
-    int rc = ensure_tuned(s, dc, pm, fuel, m->tiles[k]);
+    // asynchronous on the replica's own stream (the counting variant when stats are wanted: they are read back after the gather)
+    int rc = run(s, dc, pm, fuel, m->tiles[k], false, nullptr, stats != nullptr, false);
     if (rc != RTC_OK) return rc;
-    rtc_stats st;
-    rc = run(s, dc, pm, fuel, m->tiles[k], false, stats ? &st : nullptr, stats != nullptr, false);
-    if (rc != RTC_OK) return rc;
-    if (stats) {
-      stats->pixels += st.pixels; stats->rays_primary += st.rays_primary; stats->rays_shadow += st.rays_shadow; stats->rays_reflect += st.rays_reflect;
-      stats->rays_refract += st.rays_refract; stats->rays_container += st.rays_container; stats->accel_nodes += st.accel_nodes; stats->group_tests += st.group_tests;
-      stats->tri_tests += st.tri_tests; stats->analytic_tests += st.analytic_tests; stats->nan_ts += st.nan_ts; stats->n_launches += st.n_launches;
-      stats->accel_nodes_kernarg += st.accel_nodes_kernarg; stats->analytic_tests_kernarg += st.analytic_tests_kernarg;
-      stats->light_grid_cells += st.light_grid_cells;
-      stats->kernel_ms = std::max(stats->kernel_ms, st.kernel_ms);
-    }
     HIP_OK(hipSetDevice(s->device));
     if (q8) {  // Color::clamp on the replica's own device, behind its trace kernels
       rtc_launch_quantize(m->tiles[k], m->tiles8[k], rows * rowlen, s->stream);
@@ -760,7 +934,7 @@ int render_multi(rtc_multi* m, const rtc_camera* cam, int32_t fuel, double* rgb_
   // de-interleave pass writes the image (row k + n j  <-  slab[k][j])
   HIP_OK(hipSetDevice(s0->device));
   for (uint32_t k = 0; k < n; k++) {
-    const uint64_t rows = k < V ? (V - k + n - 1) / n : 0;
+    const uint64_t rows = band_rows_owned(V, B, k, n);
     if (rows == 0) continue;
     rtc_scene* s = m->scenes[k];
     HIP_OK(hipStreamWaitEvent(s0->stream, m->done[k], 0));
@@ -772,24 +946,47 @@ int render_multi(rtc_multi* m, const rtc_camera* cam, int32_t fuel, double* rgb_
     HIP_OK(hipEventRecord(m->copied[k], s0->stream));
     m->copied_valid[k] = 1;
   }
-  if (q8) rtc_launch_deinterleave8(m->slab8, m->image8, (unsigned)rowlen, (unsigned)V, n, (unsigned)max_rows, s0->stream);
-  else rtc_launch_deinterleave(m->slab, image, (unsigned)rowlen, (unsigned)V, n, (unsigned)max_rows, s0->stream);
+  if (q8) rtc_launch_deinterleave8(m->slab8, m->image8, (unsigned)rowlen, (unsigned)V, n, (unsigned)max_rows, B, s0->stream);
+  else rtc_launch_deinterleave(m->slab, image, (unsigned)rowlen, (unsigned)V, n, (unsigned)max_rows, B, s0->stream);
   HIP_OK(hipGetLastError());
+  {  // the caller's pages, while the devices render (see pretouch_pages)
+    std::vector<std::thread> pool;
+    if (q8) pretouch_pages(rgb8_host, V * rowlen, &pool);
+    if (rgb_host) pretouch_pages(rgb_host, V * rowlen * sizeof(double), &pool);
+    join_all(&pool);
+  }
   if (q8) HIP_OK(hipMemcpyAsync(rgb8_host, m->image8, V * rowlen, hipMemcpyDeviceToHost, s0->stream));
   if (rgb_host) HIP_OK(hipMemcpyAsync(rgb_host, image, V * rowlen * sizeof(double), hipMemcpyDeviceToHost, s0->stream));
-  if (!sync && !rgb_host && !q8) return RTC_OK;
+  if (!sync && !rgb_host && !q8 && !stats) return RTC_OK;
   HIP_OK(hipStreamSynchronize(s0->stream));
   for (uint32_t k = 0; k < n; k++) {
-    int rc = rtc_scene_check(m->scenes[k]);   // error state of every replica's launches
-    if (rc == RTC_ERR_UNSUPPORTED) {          // an unsynchronised wavefront launch overflowed its queues: once more, synchronously (falls back by itself)
-      const uint64_t rows = k < V ? (V - k + n - 1) / n : 0;
+    rtc_scene* s = m->scenes[k];
+    const uint64_t rows = band_rows_owned(V, B, k, n);
+    HIP_OK(hipSetDevice(s->device));
+    HIP_OK(hipStreamSynchronize(s->stream));
+    DStats h;
+    int rc = read_clear_sticky(s, &h);   // counters of the replica's launch + error state of every launch since the last check
+    if (rc != RTC_OK) return rc;
+    if (h.guard) return rtc_fail(RTC_ERR_DEVICE, "traversal guard tripped (mask " + std::to_string(h.guard) + ")");
+    if (h.nan_ts) return rtc_fail(RTC_ERR_NAN, "a NaN intersection t was produced (the reference panics in Intersection::sort, src/intersection.rs:124)");
+    if (h.wf_overflow) {  // an unsynchronised wavefront launch overflowed its queues: once more, synchronously (falls back by itself)
       DPixelMap pm{};
-      pm.n = rows * H; pm.mode = 2; pm.row_first = k; pm.row_step = n;
-      rc = run(m->scenes[k], dc, pm, fuel, m->tiles[k], false, nullptr, false, true);
+      pm.n = rows * H; pm.mode = 2; pm.row_first = k; pm.row_step = n; pm.band = B;
+      rc = run(s, dc, pm, fuel, m->tiles[k], false, nullptr, false, true);
       if (rc != RTC_OK) return rc;
       return render_multi(m, cam, fuel, rgb_dev_out, rgb_host, stats, true, rgb8_host);
     }
-    if (rc != RTC_OK) return rc;
+    if (stats && rows) {
+      rtc_stats st;
+      rc = fill_stats(s, h, rows * H, &st);
+      if (rc != RTC_OK) return rc;
+      stats->pixels += st.pixels; stats->rays_primary += st.rays_primary; stats->rays_shadow += st.rays_shadow; stats->rays_reflect += st.rays_reflect;
+      stats->rays_refract += st.rays_refract; stats->rays_container += st.rays_container; stats->accel_nodes += st.accel_nodes; stats->group_tests += st.group_tests;
+      stats->tri_tests += st.tri_tests; stats->analytic_tests += st.analytic_tests; stats->nan_ts += st.nan_ts; stats->n_launches += st.n_launches;
+      stats->accel_nodes_kernarg += st.accel_nodes_kernarg; stats->analytic_tests_kernarg += st.analytic_tests_kernarg;
+      stats->light_grid_cells += st.light_grid_cells; stats->group_tests_uniform += st.group_tests_uniform;
+      stats->kernel_ms = std::max(stats->kernel_ms, st.kernel_ms);  // replicas run side by side: the slowest one
+    }
   }
   return RTC_OK;
 }
@@ -857,6 +1054,16 @@ void rtc_multi_destroy(rtc_multi* m) {
 }
 
 int rtc_multi_device_count(const rtc_multi* m) { return m ? (int)m->scenes.size() : 0; }
+
+int rtc_multi_set_band_rows(rtc_multi* m, uint32_t band_rows) {
+  if (!m || band_rows == 0) return rtc_fail(RTC_ERR_INVALID, "NULL argument / band_rows must be >= 1");
+  for (rtc_scene* s : m->scenes) {  // queued frames still use the old layout of tiles and slab
+    HIP_OK(hipSetDevice(s->device));
+    HIP_OK(hipStreamSynchronize(s->stream));
+  }
+  m->band = band_rows;
+  return RTC_OK;
+}
 
 int rtc_render_multi(rtc_multi* m, const rtc_camera* cam, int32_t fuel, double* rgb, rtc_stats* stats) {
   if (!rgb) return rtc_fail(RTC_ERR_INVALID, "NULL argument");

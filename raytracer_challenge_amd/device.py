@@ -21,10 +21,11 @@ class RtcStatsC(C.Structure):
                  "accel_nodes", "group_tests", "tri_tests", "analytic_tests", "nan_ts")
     _fields_ = [(n, C.c_uint64) for n in _COUNTERS] + \
                [("kernel_ms", C.c_double), ("n_launches", C.c_uint32), ("_pad", C.c_uint32),
-                ("accel_nodes_kernarg", C.c_uint64), ("analytic_tests_kernarg", C.c_uint64), ("light_grid_cells", C.c_uint64)]
+                ("accel_nodes_kernarg", C.c_uint64), ("analytic_tests_kernarg", C.c_uint64), ("light_grid_cells", C.c_uint64),
+                ("group_tests_uniform", C.c_uint64)]
 
     def as_dict(self):
-        d = {n: int(getattr(self, n)) for n in self._COUNTERS + ("accel_nodes_kernarg", "analytic_tests_kernarg", "light_grid_cells")}
+        d = {n: int(getattr(self, n)) for n in self._COUNTERS + ("accel_nodes_kernarg", "analytic_tests_kernarg", "light_grid_cells", "group_tests_uniform")}
         d["kernel_ms"] = float(self.kernel_ms)
         d["n_launches"] = int(self.n_launches)
         d["unique_rays"] = d["rays_primary"] + d["rays_shadow"] + d["rays_reflect"] + d["rays_refract"]
@@ -43,7 +44,7 @@ UNIT_BYTES = {
     "pixel": 24,      # framebuffer write (3 x f64)
     "light_cell": 16, # one light-grid lookup of a shadow ray: two 4-B cell offsets + on average two 4-B candidate references
 }
-KERNARG_BYTES = {"node": 128, "plane": 48}
+KERNARG_BYTES = {"node": 128, "plane": 48, "group_box": 48}
 
 
 def algorithmic_bytes(st: dict, path: str, n_prims: int = 0, lds_tables: bool = False) -> dict:
@@ -61,7 +62,8 @@ def algorithmic_bytes(st: dict, path: str, n_prims: int = 0, lds_tables: bool = 
     by_unit = {
         "ray": UNIT_BYTES["ray"] * st["unique_rays"] if wavefront else 0,
         "node": 0 if lds else node_b,
-        "group_box": UNIT_BYTES["group_box"] * st["group_tests"],
+        # gates named by a kernel-argument program test ONE box per wave (scalar loads of a uniform address): kernarg class, 0 bytes
+        "group_box": UNIT_BYTES["group_box"] * (st["group_tests"] - st.get("group_tests_uniform", 0)),
         "triangle": 0 if lds else tri_b,
         "analytic": 0 if lds else ana_b,
         "pixel": UNIT_BYTES["pixel"] * st["pixels"],
@@ -71,7 +73,8 @@ def algorithmic_bytes(st: dict, path: str, n_prims: int = 0, lds_tables: bool = 
     ideal = 96 + 64 * math.ceil(math.log2(max(2, n_prims))) + 72 * 4
     cap = 4 * ideal * st["unique_rays"] + UNIT_BYTES["pixel"] * st["pixels"]
     return {"memory": min(counted, cap), "counted": counted, "cap_4x_ideal": cap,
-            "kernarg": KERNARG_BYTES["node"] * st["accel_nodes_kernarg"] + KERNARG_BYTES["plane"] * st["analytic_tests_kernarg"],
+            "kernarg": KERNARG_BYTES["node"] * st["accel_nodes_kernarg"] + KERNARG_BYTES["plane"] * st["analytic_tests_kernarg"]
+                       + KERNARG_BYTES["group_box"] * st.get("group_tests_uniform", 0),
             "lds": (node_b + tri_b + ana_b) if lds else 0,
             "by_unit": by_unit, "unit_bytes": UNIT_BYTES}
 
@@ -90,9 +93,9 @@ class DeviceRenderer:
         lib.rtw_world_scene.argtypes = [C.c_void_p, C.c_int]
         lib.rtw_make_camera.restype = C.c_int
         lib.rtw_make_camera.argtypes = [C.POINTER(CameraC), C.POINTER(RtcCameraC)]
-        lib.rtc_render_rows_device.restype = C.c_int
-        lib.rtc_render_rows_device.argtypes = [C.c_void_p, C.POINTER(RtcCameraC), C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32,
-                                               C.c_void_p, C.POINTER(RtcStatsC), C.c_int, C.c_int]
+        lib.rtc_render_bands_device.restype = C.c_int
+        lib.rtc_render_bands_device.argtypes = [C.c_void_p, C.POINTER(RtcCameraC), C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                C.c_void_p, C.POINTER(RtcStatsC), C.c_int, C.c_int]
         lib.rtc_scene_sync.restype = C.c_int
         lib.rtc_scene_sync.argtypes = [C.c_void_p]
         for name in ("rtc_scene_record", "rtc_scene_wait"):
@@ -119,29 +122,31 @@ class DeviceRenderer:
             raise RtwError("camera: %s" % backend._err())
 
     def render_rows(self, fuel: int, row_first: int, row_step: int, n_rows: int, out_tensor, count: bool = False, sync: bool = True,
-                    want_stats: bool = True) -> dict:
-        """Rows row_first, row_first+row_step, ... (n_rows) -> out_tensor (float64, n_rows*hsize*3, on this scene's GPU)."""
+                    want_stats: bool = True, band_rows: int = 1) -> dict:
+        """The first n_rows rows of the dense tile of part `row_first` of `row_step` -> out_tensor (float64, n_rows*hsize*3, on this
+        scene's GPU).  band_rows = 1: image rows row_first, row_first+row_step, ...; band_rows = B: bands of B rows dealt out the
+        same way (include/rtc.h rtc_render_bands_device; parallel.BAND_ROWS = 8 is the multi-GPU partition)."""
         need = n_rows * self.camera.hsize * 3
         if out_tensor.numel() < need or out_tensor.element_size() != 8 or not (out_tensor.is_cuda or self._cpu_standin):
             raise RtwError("output tensor must be a float64 device tensor with >= %d elements" % need)
         st = RtcStatsC()
-        rc = self.backend.lib.rtc_render_rows_device(self.scene, C.byref(self.cam), int(fuel), int(row_first), int(row_step), int(n_rows),
-                                                     C.c_void_p(out_tensor.data_ptr()), C.byref(st) if want_stats else None, 1 if count else 0, 1 if sync else 0)
+        rc = self.backend.lib.rtc_render_bands_device(self.scene, C.byref(self.cam), int(fuel), int(band_rows), int(row_first), int(row_step), int(n_rows),
+                                                      C.c_void_p(out_tensor.data_ptr()), C.byref(st) if want_stats else None, 1 if count else 0, 1 if sync else 0)
         if rc != 0:
-            raise RtwError("rtc_render_rows_device: %s" % (self.backend.lib.rtc_last_error() or b"").decode())
+            raise RtwError("rtc_render_bands_device: %s" % (self.backend.lib.rtc_last_error() or b"").decode())
         return st.as_dict() if want_stats else {}
 
     def _rc(self, rc, what):
         if rc != 0:
             raise RtwError("%s: %s" % (what, (self.backend.lib.rtc_last_error() or b"").decode()))
 
-    def render_rows_async(self, fuel: int, row_first: int, row_step: int, n_rows: int, out_tensor):
+    def render_rows_async(self, fuel: int, row_first: int, row_step: int, n_rows: int, out_tensor, band_rows: int = 1):
         """Queue a render on the scene's stream and return immediately (errors are reported by check())."""
         need = n_rows * self.camera.hsize * 3
         if out_tensor.numel() < need or out_tensor.element_size() != 8 or not (out_tensor.is_cuda or self._cpu_standin):
             raise RtwError("output tensor must be a float64 device tensor with >= %d elements" % need)
-        self._rc(self.backend.lib.rtc_render_rows_device(self.scene, C.byref(self.cam), int(fuel), int(row_first), int(row_step), int(n_rows),
-                                                        C.c_void_p(out_tensor.data_ptr()), None, 0, 0), "rtc_render_rows_device")
+        self._rc(self.backend.lib.rtc_render_bands_device(self.scene, C.byref(self.cam), int(fuel), int(band_rows), int(row_first), int(row_step), int(n_rows),
+                                                         C.c_void_p(out_tensor.data_ptr()), None, 0, 0), "rtc_render_bands_device")
 
     def record(self, slot: int):
         self._rc(self.backend.lib.rtc_scene_record(self.scene, slot), "rtc_scene_record")
@@ -160,11 +165,11 @@ class DeviceRenderer:
     def sync(self):
         self.backend.lib.rtc_scene_sync(self.scene)
 
-    def tune(self, fuel: int, row_first: int, row_step: int, n_rows: int, out_tensor) -> dict:
+    def tune(self, fuel: int, row_first: int, row_step: int, n_rows: int, out_tensor, band_rows: int = 1) -> dict:
         """Lets the library measure both device paths for this launch shape (four synchronous renders into out_tensor, two
         per path) so that later launches, including unsynchronised ones, take the faster; returns path_info()."""
         for _ in range(4):
-            self.render_rows(fuel, row_first, row_step, n_rows, out_tensor, count=False, sync=True, want_stats=False)
+            self.render_rows(fuel, row_first, row_step, n_rows, out_tensor, count=False, sync=True, want_stats=False, band_rows=band_rows)
         return self.path_info()
 
     def path_info(self) -> dict:

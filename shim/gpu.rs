@@ -140,6 +140,7 @@ pub struct RtcStats {
     pub accel_nodes_kernarg: u64,
     pub analytic_tests_kernarg: u64,
     pub light_grid_cells: u64,
+    pub group_tests_uniform: u64,
 }
 
 pub enum RtcScene {}
@@ -160,6 +161,8 @@ extern "C" {
     fn rtc_render_multi(multi: *mut RtcMulti, camera: *const RtcCamera, fuel: i32, rgb: *mut f64, stats: *mut RtcStats) -> c_int;
     #[allow(dead_code)] // Color::clamp'ed pixels (what Image::ppm writes): 3 bytes per pixel cross xGMI instead of 24
     fn rtc_render_multi_rgb8(multi: *mut RtcMulti, camera: *const RtcCamera, fuel: i32, rgb8: *mut u8, stats: *mut RtcStats) -> c_int;
+    #[allow(dead_code)] // the same on one device: quantised on the GPU, 3 bytes per pixel cross PCIe
+    fn rtc_render_rgb8(scene: *mut RtcScene, camera: *const RtcCamera, fuel: i32, rgb8: *mut u8, stats: *mut RtcStats) -> c_int;
 }
 
 #[derive(Debug)]

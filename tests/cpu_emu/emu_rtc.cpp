@@ -25,7 +25,8 @@ struct rtc_scene {
 static thread_local std::string g_err;
 static int efail(int c, const std::string& m) { g_err = m; return c; }
 
-static int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* rgb, rtc_hit* hits, rtc_stats* stats) {
+static int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* rgb, rtc_hit* hits, rtc_stats* stats, unsigned long long* digest = nullptr) {
+  pm.digest = digest;
   if (fuel < 0) fuel = 0;
   if (fuel > RTC_MAX_FUEL) return efail(RTC_ERR_INVALID, "fuel exceeds RTC_MAX_FUEL");
   std::vector<double> t(hits ? pm.n : 0);
@@ -49,6 +50,8 @@ static int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double*
       std::vector<unsigned char> mem(dwave_bytes(cap, lv), 0xCD);  // hipMalloc does not zero either: nothing may rely on it
       DWave W{};
       dwave_carve(&W, mem.data(), cap, lv);
+      std::vector<unsigned long long> dig(digest ? cap * (uint64_t)lv : 0, 0xCDCDCDCDCDCDCDCDull);
+      if (digest) W.dig = dig.data();
       std::memset(W.counts, 0, RTC_WF_COUNTS * sizeof(uint32_t));
       std::memset(&st, 0, sizeof(st));
       rtc_launch_wavefront(s->d, cam, pm, fuel, W, rgb, hits ? t.data() : nullptr, p.data(), k.data(), &st, true, nullptr, 5, 3);
@@ -70,6 +73,7 @@ static int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double*
     stats->rays_container = st.rays_container; stats->accel_nodes = st.accel_nodes; stats->group_tests = st.group_tests; stats->tri_tests = st.tri_tests;
     stats->analytic_tests = st.analytic_tests; stats->nan_ts = st.nan_ts;
     stats->accel_nodes_kernarg = st.knodes; stats->analytic_tests_kernarg = st.kplanes; stats->light_grid_cells = st.light_cells;
+    stats->group_tests_uniform = st.kgroups;
     stats->n_launches = n_launches;
   }
   if (st.guard) return efail(RTC_ERR_DEVICE, "traversal guard tripped (mask " + std::to_string(st.guard) + ")");
@@ -115,12 +119,50 @@ int rtc_render(rtc_scene* s, const rtc_camera* cam, int32_t fuel, const uint64_t
   to_dcam(*cam, &dc);
   return run(s, dc, pm, fuel, rgb, hits, stats);
 }
-int rtc_render_rows_device(rtc_scene* s, const rtc_camera* cam, int32_t fuel, uint32_t row_first, uint32_t row_step, uint32_t n_rows, double* rgb, rtc_stats* stats, int, int) {
+int rtc_render_bands_device(rtc_scene* s, const rtc_camera* cam, int32_t fuel, uint32_t band_rows, uint32_t band_first, uint32_t band_step, uint32_t n_rows, double* rgb,
+                            rtc_stats* stats, int, int) {
+  if (band_rows == 0 || band_step == 0) return efail(RTC_ERR_INVALID, "band_rows and band_step must be >= 1");
   DPixelMap pm{};
-  pm.n = (uint64_t)n_rows * cam->hsize; pm.mode = 2; pm.row_first = row_first; pm.row_step = row_step;
+  pm.n = (uint64_t)n_rows * cam->hsize; pm.mode = 2; pm.row_first = band_first; pm.row_step = band_step; pm.band = band_rows;
   DCamera dc;
   to_dcam(*cam, &dc);
   return run(s, dc, pm, fuel, rgb, nullptr, stats);
+}
+int rtc_render_rows_device(rtc_scene* s, const rtc_camera* cam, int32_t fuel, uint32_t row_first, uint32_t row_step, uint32_t n_rows, double* rgb, rtc_stats* stats, int a, int b) {
+  return rtc_render_bands_device(s, cam, fuel, 1, row_first, row_step, n_rows, rgb, stats, a, b);
+}
+uint64_t rtc_band_rows_owned(uint64_t vsize, uint32_t band, uint32_t first, uint32_t step) {  // as the product (rtc_scene.cpp)
+  if (band == 0 || step == 0) return 0;
+  const uint64_t n_bands = (vsize + band - 1) / band;
+  if (first >= n_bands) return 0;
+  const uint64_t mine = (n_bands - first + step - 1) / step;
+  uint64_t rows = mine * band;
+  if (first + (mine - 1) * (uint64_t)step == n_bands - 1) rows -= n_bands * band - vsize;
+  return rows;
+}
+int rtc_render_hit_digest(rtc_scene* s, const rtc_camera* cam, int32_t fuel, const uint64_t* idx, uint64_t first, uint64_t n, uint64_t* digest) {
+  DPixelMap pm{};
+  pm.n = n;
+  std::vector<uint64_t> range_idx;
+  if (!idx) {
+    if (first % cam->hsize == 0 && n % cam->hsize == 0) { pm.mode = 2; pm.row_first = (uint32_t)(first / cam->hsize); pm.row_step = 1; }
+    else { range_idx.resize(n); for (uint64_t i = 0; i < n; i++) range_idx[i] = first + i; idx = range_idx.data(); }
+  }
+  if (idx) { pm.mode = 1; pm.indices = idx; }
+  DCamera dc;
+  to_dcam(*cam, &dc);
+  std::vector<double> rgb(3 * n);
+  static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "digest type");
+  return run(s, dc, pm, fuel, rgb.data(), nullptr, nullptr, (unsigned long long*)digest);
+}
+int rtc_quantize_device(rtc_scene*, const double* rgb, uint64_t n, uint8_t* out, int);
+int rtc_render_rgb8(rtc_scene* s, const rtc_camera* cam, int32_t fuel, uint8_t* rgb8, rtc_stats* stats) {
+  if (!s || !cam || !rgb8) return efail(RTC_ERR_INVALID, "NULL argument");
+  const uint64_t n = cam->hsize * cam->vsize;
+  std::vector<double> rgb(3 * n);
+  int rc = rtc_render(s, cam, fuel, nullptr, 0, n, rgb.data(), nullptr, stats);
+  if (rc != RTC_OK) return rc;
+  return rtc_quantize_device(s, rgb.data(), 3 * n, rgb8, 1);
 }
 int rtc_trace_rays(rtc_scene* s, const double* rays, uint64_t n, int32_t fuel, double* rgb, rtc_hit* hits, rtc_stats* stats) {
   DPixelMap pm{};

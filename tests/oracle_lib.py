@@ -30,6 +30,8 @@ class OracleBackend(Backend):
         vp = C.c_void_p
         self.lib.orc_render.restype = C.c_int
         self.lib.orc_render.argtypes = [vp, vp, C.c_int, vp, C.c_uint64, vp, vp, C.c_uint32, C.POINTER(OrcStats)]
+        self.lib.orc_render_ex.restype = C.c_int
+        self.lib.orc_render_ex.argtypes = [vp, vp, C.c_int, vp, C.c_uint64, vp, vp, C.c_uint32, C.POINTER(OrcStats), vp]
         self.lib.orc_ppm.restype = C.c_uint64
         self.lib.orc_ppm.argtypes = [C.c_uint64, C.c_uint64, vp, C.c_char_p, C.c_uint64]
         self.lib.orc_quantize.restype = None
@@ -51,6 +53,20 @@ class OracleBackend(Backend):
         st = OrcStats()
         self._check(self.lib.orc_render(nw.handle, C.byref(cam), int(fuel), idx_p, n, rgb.ctypes.data, hits.ctypes.data, threads, C.byref(st)), "orc_render")
         return rgb, hits, st
+
+    def render_with_digest(self, nw, camera, fuel, pixel_indices=None, threads=0):
+        """One oracle pass: (rgb, primary hits, hit-tree digests) of the pixels."""
+        cam = self.camera_c(camera)
+        if pixel_indices is None:
+            n, idx_p = camera.hsize * camera.vsize, None
+        else:
+            pixel_indices = np.ascontiguousarray(pixel_indices, dtype=np.uint64)
+            n, idx_p = pixel_indices.size, pixel_indices.ctypes.data
+        rgb = np.empty((n, 3), dtype=np.float64)
+        hits = np.empty(n, dtype=HIT_DTYPE)
+        dig = np.empty(n, dtype=np.uint64)
+        self._check(self.lib.orc_render_ex(nw.handle, C.byref(cam), int(fuel), idx_p, n, rgb.ctypes.data, hits.ctypes.data, threads, None, dig.ctypes.data), "orc_render_ex")
+        return rgb, hits, dig
 
     def quantize(self, rgb):
         rgb = np.ascontiguousarray(rgb, dtype=np.float64)

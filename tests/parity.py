@@ -4,14 +4,32 @@ import numpy as np
 RGB_TOL = 1e-5  # BASELINE.json north_star: "pixels match the reference CPU render within 1e-5 per RGB channel"
 
 
-def assert_parity(test_backend, orc, world, camera, fuel=5, pixel_indices=None, label=""):
-    """Hit records must be bit-exact (t as u64 bits, primitive sequence number, push index); colours within RGB_TOL."""
-    nw_t, nw_o = test_backend.build_world(world), orc.build_world(world)
+def oracle_reference(orc, world, camera, fuel=5, pixel_indices=None, threads=0):
+    """One oracle pass (rgb, primary hits, hit-tree digests), to be shared by several assert_parity calls on the same scene."""
+    return orc.render_with_digest(orc.build_world(world), camera, fuel, pixel_indices, threads=threads)
+
+
+def assert_parity(test_backend, orc, world, camera, fuel=5, pixel_indices=None, label="", digest=True, ref=None):
+    """Hit records must be bit-exact: the primary hit of every pixel (t as u64 bits, primitive sequence number, push index) and,
+    through the hit-tree digest (include/rtc.h rtc_render_hit_digest), every closest hit of every pixel's ray tree — reflected and
+    refracted rays at every depth; colours within RGB_TOL."""
+    nw_t = test_backend.build_world(world)
     rgb, hits = test_backend.render(nw_t, camera, fuel, pixel_indices)
-    ref_rgb, ref_hits = orc.render(nw_o, camera, fuel, pixel_indices)
+    ref_dig = None
+    if ref is not None:
+        ref_rgb, ref_hits, ref_dig = ref
+    elif digest:
+        ref_rgb, ref_hits, ref_dig = orc.render_with_digest(orc.build_world(world), camera, fuel, pixel_indices)
+    else:
+        ref_rgb, ref_hits = orc.render(orc.build_world(world), camera, fuel, pixel_indices)
     bad = (hits["prim"] != ref_hits["prim"]) | (hits["push_idx"] != ref_hits["push_idx"]) | (hits["t"].view(np.uint64) != ref_hits["t"].view(np.uint64))
     assert not bad.any(), "%s: %d/%d primary-hit records differ, first at %s: got %s want %s" % (
         label, int(bad.sum()), bad.size, np.flatnonzero(bad)[:3], hits[bad][:3], ref_hits[bad][:3])
+    if ref_dig is not None:
+        dig = test_backend.render_digest(nw_t, camera, fuel, pixel_indices)
+        bad_d = dig != ref_dig
+        assert not bad_d.any(), "%s: the hit-tree digests of %d/%d pixels differ (a closest hit somewhere below the primary one), first at %s" % (
+            label, int(bad_d.sum()), bad_d.size, np.flatnonzero(bad_d)[:5])
     err = float(np.abs(rgb - ref_rgb).max()) if rgb.size else 0.0
     assert err <= RGB_TOL, "%s: max |dRGB| = %.3e > %.0e" % (label, err, RGB_TOL)
     return err

@@ -186,4 +186,49 @@ def test_hip_render_multi_equals_one_device(hip, devices):
             assert lib.rtc_render_multi_device(m, C.byref(rc), 5, C.c_void_p(out.data_ptr()), 0) == 0, lib.rtc_last_error()
         assert lib.rtc_multi_sync(m) == 0, lib.rtc_last_error()
         assert np.array_equal(out.cpu().numpy().reshape(-1, 3), want_rgb), (name, devices)
+        # the counters of the replicas' (side by side, asynchronous) counting launches add up to the one-device launch's
+        lib.rtc_render.restype = C.c_int
+        one = RtcStatsC()
+        scene = vp()
+        assert lib.rtc_scene_create(C.byref(desc), 0, C.byref(scene)) == 0
+        rgb3 = np.empty((n, 3))
+        assert lib.rtc_render(scene, C.byref(rc), 5, None, 0, n, rgb3.ctypes.data, None, C.byref(one)) == 0, lib.rtc_last_error()
+        lib.rtc_scene_destroy(scene)
+        for f in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "rays_container", "analytic_tests_kernarg"):
+            assert getattr(st, f) == getattr(one, f), (f, name, devices)
+        # other band heights (default 8): single rows interleaved, and a height that leaves a short last band
+        lib.rtc_multi_set_band_rows.restype = C.c_int
+        lib.rtc_multi_set_band_rows.argtypes = [vp, C.c_uint32]
+        for band in (1, 5):
+            assert lib.rtc_multi_set_band_rows(m, band) == 0
+            rgb4 = np.full((n, 3), np.nan)
+            assert lib.rtc_render_multi(m, C.byref(rc), 5, rgb4.ctypes.data, None) == 0, lib.rtc_last_error()
+            assert np.array_equal(rgb4, want_rgb), (name, devices, band)
+        assert lib.rtc_multi_set_band_rows(m, 0) != 0
         lib.rtc_multi_destroy(m)
+
+
+@pytest.mark.gpu
+def test_hip_render_rgb8_is_color_clamp_of_the_f64_frame(hip):
+    """rtc_render_rgb8: the frame quantised on the device (src/color.rs:42-46), 3 bytes per pixel to the host."""
+    lib = bind(hip.lib)
+    vp = C.c_void_p
+    from raytracer_challenge_amd.device import RtcStatsC
+    lib.rtc_render_rgb8.restype = C.c_int
+    lib.rtc_render_rgb8.argtypes = [vp, C.POINTER(ff.RtcCamera), C.c_int32, vp, C.POINTER(RtcStatsC)]
+    for name in ("synthetic_cones_grouped", "nested_glass"):
+        cam, world = (DESC_CASES.get(name) or cases.SMALL_CASES[name])()
+        rgb, _, flat = render_desc(lib, world, cam)
+        desc = flat.desc()
+        scene = vp()
+        assert lib.rtc_scene_create(C.byref(desc), 0, C.byref(scene)) == 0
+        rc = ff.make_camera(cam)
+        rgb8 = np.zeros(rgb.size, dtype=np.uint8)
+        st = RtcStatsC()
+        assert lib.rtc_render_rgb8(scene, C.byref(rc), 5, rgb8.ctypes.data, C.byref(st)) == 0, lib.rtc_last_error()
+        lib.rtc_scene_destroy(scene)
+        c = np.where(np.isnan(rgb.reshape(-1)), 1.0, np.minimum(rgb.reshape(-1), 1.0))
+        want8 = np.floor(np.maximum(c, 0.0) * 255.0 + 0.5).astype(np.uint8)
+        assert np.array_equal(rgb8, want8), name
+        assert st.pixels == cam.hsize * cam.vsize
+        assert lib.rtc_render_rgb8(scene if False else None, C.byref(rc), 5, rgb8.ctypes.data, None) != 0   # NULL scene is refused
