@@ -181,8 +181,9 @@ int rtc_render_hit_digest(rtc_scene*, const rtc_camera*, int32_t fuel, const uin
 int rtc_render_rgb8(rtc_scene*, const rtc_camera*, int32_t fuel, uint8_t* rgb8, rtc_stats* stats);
 
 /* Host buffers handed to rtc_render / rtc_render_rgb8 / rtc_render_multi* / rtc_trace_rays are written by the device copy
- * directly; while the device renders, the library touches their pages from a few host threads (a freshly allocated Vec / calloc
- * buffer has none yet; RTC_PRETOUCH_THREADS, default 8, 0 = off), so on an error return their contents are unspecified. */
+ * directly (one copy per array, queued behind the kernels; hit records are packed on the device); on an error return their
+ * contents are unspecified.  RTC_PRETOUCH_THREADS=n (default 0: measured slower than the copy's own page handling) lets n host
+ * threads write one byte to each destination page while the device renders. */
 
 /* Same, output left in device memory (rgb_dev: n*3 doubles on the scene's device), for the rows
  * row_first, row_first+row_step, ... (n_rows of them) — the tile-interleaved multi-GPU partition.

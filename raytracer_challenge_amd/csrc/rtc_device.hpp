@@ -1396,7 +1396,10 @@ __global__ void __launch_bounds__(RTC_BLOCK, WAVES ? WAVES : ((FEAT >= 2 && RTC_
   if (have) {
     Ray ray = slot_ray(pm, cam, q);
 
-    Pending pend[RTC_MAX_FUEL];
+#ifndef RTC_PEND_MAX
+#define RTC_PEND_MAX RTC_MAX_FUEL
+#endif
+    Pending pend[RTC_PEND_MAX];
     int np = 0;
     double acc_r = 0.0, acc_g = 0.0, acc_b = 0.0;
     double weight = 1.0;
@@ -1461,7 +1464,11 @@ __global__ void __launch_bounds__(RTC_BLOCK, WAVES ? WAVES : ((FEAT >= 2 && RTC_
           double w = mi[12] * st.px + mi[13] * st.py + mi[14] * st.pz + mi[15] * 1.0;
           const DPat& root = S.pats[S.mat_pattern[P.mat]];
           if (root.tag == 1) { cr = root.color[0]; cg = root.color[1]; cb = root.color[2]; }
+#ifdef RTC_NO_PATTERNS
+          else { cr = cg = cb = 0.0; }
+#else
           else pattern_color(S, S.mat_pattern[P.mat], x, y, z, w, cr, cg, cb);
+#endif
         }
 
         DIAG_REGION(2);

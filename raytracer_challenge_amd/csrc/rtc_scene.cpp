@@ -131,22 +131,24 @@ int ensure_px(rtc_scene* s, uint64_t n, bool hits) {
 }
 
 // ---- device -> host for the caller's output buffers (Image::par_render returns host pixels, src/image.rs:76-80) ----------------
-// Measured on the GPU box (scripts/d2h_probe.hip, profiles/r3_d2h_probe.txt): a pageable hipMemcpy runs at PCIe speed (52-56 GB/s)
-// once the destination's pages exist; what made round 2's rtc_render 13x slower than its kernels was the destination itself —
-// a freshly allocated buffer (Vec / calloc / numpy.empty) has no pages yet and they were faulted in one by one inside the copy —
-// plus three temporary vectors and a scalar host loop for the hit records.  So: (1) while the device renders, a few host threads
-// touch the destination's pages (each page's first byte is written back to itself: contents unchanged, page present);
-// (2) hit records are packed on the device into the caller's layout; (3) one copy per output array, straight into the caller's
-// memory, queued on the scene's stream behind the kernels.
+// Measured on the GPU box (scripts/d2h_probe.hip, profiles/r3_d2h_probe.txt): a pageable hipMemcpy runs at PCIe speed (52-56 GB/s,
+// 1.0 ms per 50 MB) when the destination's pages exist and at 2.4 ms per 50 MB into a freshly allocated buffer (Vec / calloc /
+// numpy.empty: the runtime pins the range, which faults its pages in in bulk).  What made round 2's rtc_render 13x slower than its
+// kernels was everything around that copy: three temporary vectors and a scalar host loop for the hit records, and a host sync
+// between the kernels and the first copy.  So: (1) hit records are packed on the device into the caller's layout; (2) one copy per
+// output array, straight into the caller's memory, queued on the scene's stream behind the kernels.
+// Touching the destination's pages from host threads while the device renders was measured too and is OFF by default
+// (RTC_PRETOUCH_THREADS=n turns it on): 3.5 ms per 50 MB with 8 threads writing one byte per page (page faults of one address space
+// serialise in the kernel) — and 22 ms when the page was read first (zero page mapped, then a second, copy-on-write fault).
 void pretouch_pages(void* p, size_t bytes, std::vector<std::thread>* pool) {
   if (!p || bytes < (4u << 20)) return;
-  static const int T = [] { const char* e = std::getenv("RTC_PRETOUCH_THREADS"); int t = e ? std::atoi(e) : 8; return t < 0 ? 0 : (t > 32 ? 32 : t); }();
+  static const int T = [] { const char* e = std::getenv("RTC_PRETOUCH_THREADS"); int t = e ? std::atoi(e) : 0; return t < 0 ? 0 : (t > 32 ? 32 : t); }();
   if (T == 0) return;
   char* base = (char*)p;
   const size_t per = ((bytes / (size_t)T) + 4095) & ~(size_t)4095;
   for (int t = 0; t < T; t++) {
     const size_t b = std::min(bytes, per * (size_t)t), e = std::min(bytes, per * (size_t)(t + 1));
-    if (e > b) pool->emplace_back([base, b, e] { for (size_t o = b; o < e; o += 4096) { volatile char* q = base + o; *q = *q; } });
+    if (e > b) pool->emplace_back([base, b, e] { for (size_t o = b; o < e; o += 4096) { volatile char* q = base + o; *q = 0; } });
   }
 }
 void join_all(std::vector<std::thread>* pool) {

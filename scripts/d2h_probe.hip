@@ -62,7 +62,40 @@ static int oneshot(const char* mode, size_t n, bool untouched) {
   return 0;
 }
 
+// Steady state of a caller that hands a NEW destination to every render (Image::par_render returns a fresh Vec; numpy.empty):
+// per iteration a fresh malloc (mmap'd: no pages), optionally touched by T threads — one zero byte per 4 KB page, write only (a read
+// first would map the shared zero page and pay a second, copy-on-write fault) — then one pageable hipMemcpy.
+static int steady(size_t n) {
+  CK(hipSetDevice(0));
+  void* dev = nullptr;
+  CK(hipMalloc(&dev, n));
+  CK(hipMemset(dev, 1, n));
+  { char* w = (char*)std::malloc(n); std::memset(w, 0, n); CK(hipMemcpy(w, dev, n, hipMemcpyDeviceToHost)); std::free(w); }  // first-copy costs
+  for (int T : {0, 1, 2, 4, 8, 16}) {
+    double tt = 0.0, tc = 0.0;
+    const int reps = 5;
+    for (int r = 0; r < reps; r++) {
+      char* dst = (char*)std::malloc(n);
+      double t0 = now();
+      if (T > 0) {
+        std::vector<std::thread> th;
+        const size_t per = ((n / T) + 4095) & ~size_t(4095);
+        for (int t = 0; t < T; t++) th.emplace_back([=] { for (size_t o = per * t; o < std::min(n, per * (t + 1)); o += 4096) { volatile char* p = dst + o; *p = 0; } });
+        for (auto& t : th) t.join();
+      }
+      double t1 = now();
+      CK(hipMemcpy(dst, dev, n, hipMemcpyDeviceToHost));
+      double t2 = now();
+      tt += t1 - t0; tc += t2 - t1;
+      std::free(dst);
+    }
+    std::printf("steady %4zu MiB, fresh destination per copy, %2d touch thread(s): touch %.2f ms + hipMemcpy %.2f ms = %.2f ms\n", n >> 20, T, tt / reps * 1e3, tc / reps * 1e3, (tt + tc) / reps * 1e3);
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 3 && !std::strcmp(argv[1], "steady")) return steady((size_t)std::atoi(argv[2]) << 20);
   if (argc >= 4) return oneshot(argv[1], (size_t)std::atoi(argv[2]) << 20, argv[3][0] == '1');
   CK(hipSetDevice(0));
   const size_t sizes[] = {50ull << 20, 83ull << 20, 200ull << 20};
