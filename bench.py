@@ -259,15 +259,27 @@ def host_pixel_times(hip, dr, nw, cam, fuel, reps=5):
     keep_rgb, keep_hits, keep8 = np.zeros((n, 3)), np.zeros(n, dtype=HIT_DTYPE), np.zeros(3 * n, dtype=np.uint8)
     call(keep_rgb, keep_hits)
     call8(keep8)
+
+    def timed_fresh(make, fn):
+        """`reps` calls, each into a destination allocated BEFORE the clock starts and never touched (numpy.empty: no pages yet)."""
+        bufs = [make() for _ in range(reps)]
+        ts = []
+        for b in bufs:
+            t = time.perf_counter()
+            fn(b)
+            ts.append((time.perf_counter() - t) * 1e3)
+        return float(np.median(ts))
+
     out = {
-        "f64_fresh_buffer_ms": timed(lambda: call(np.empty((n, 3)), None)),
         "f64_reused_buffer_ms": timed(lambda: call(keep_rgb, None)),
-        "f64_with_hits_fresh_buffers_ms": timed(lambda: call(np.empty((n, 3)), np.empty(n, dtype=HIT_DTYPE))),
-        "rgb8_fresh_buffer_ms": timed(lambda: call8(np.empty(3 * n, dtype=np.uint8))),
+        "f64_fresh_buffer_ms": timed_fresh(lambda: np.empty((n, 3)), lambda b: call(b, None)),
+        "f64_with_hits_reused_buffers_ms": timed(lambda: call(keep_rgb, keep_hits)),
         "rgb8_reused_buffer_ms": timed(lambda: call8(keep8)),
+        "rgb8_fresh_buffer_ms": timed_fresh(lambda: np.empty(3 * n, dtype=np.uint8), call8),
         "bytes": {"f64": 24 * n, "hits": 16 * n, "rgb8": 3 * n},
-        "note": "wall clock of the blocking C-ABI call (kernels + copy to the caller's pageable memory), median of %d; fresh = a new numpy.empty "
-                "destination per call (no pages yet: the library touches them from host threads while the device renders)" % reps,
+        "note": "wall clock of the blocking C-ABI call (kernels + one copy per array into the caller's pageable memory), median of %d.  reused = the "
+                "destination's pages exist (PCIe rate: ~1.0 ms per 50 MB); fresh = a never-touched numpy.empty destination per call: the copy also "
+                "faults the caller's new pages in (kernel mm work of the caller's allocation, ~+1.4 ms per 50 MB in scripts/d2h_probe.hip)" % reps,
     }
     return out
 
@@ -327,7 +339,7 @@ def one_shot_child(name):
     print(json.dumps({"one_shot": name, "hsize": H, "vsize": V, "fuel": fuel,
                       "import_ms": (t0 - t_start) * 1e3, "build_world_ms": (t1 - t0) * 1e3, "create_ms": (t2 - t1) * 1e3,
                       "first_render_to_host_ms": (t4 - t3) * 1e3, "second_render_to_host_ms": (t6 - t5) * 1e3,
-                      "kernel_ms_counting_variant": st.kernel_ms, "obj_parse_ms": obj_parse_ms,
+                      "kernel_ms_of_a_counting_launch_not_the_timed_kernels": st.kernel_ms, "obj_parse_ms": obj_parse_ms,
                       "total_ms": (t4 - t0) * 1e3, "first_launch_path": "wavefront" if st.n_launches > 1 else "one kernel", "path_info": pi,
                       "equal": bool(np.array_equal(rgb, rgb2))}), flush=True)
 
@@ -505,7 +517,7 @@ def measure(args, rtm, dist, workload, fuel, steps, warmup, F, rank, world_size,
         # a FRESH destination every call (what `-> Image` means: a new Vec whose pages do not exist yet), into a reused one, and
         # with the primary-hit channel; wall clock around the blocking call.
         res["host_pixels"] = host_pixel_times(hip, dr, nw, cam, fuel)
-        res["ms_per_step_incl_d2h"] = res["host_pixels"]["f64_fresh_buffer_ms"]
+        res["ms_per_step_incl_d2h"] = res["host_pixels"]["f64_reused_buffer_ms"]
         rgb_full, hits_full = hip.render(nw, cam, fuel)
         if want_cpu:
             base, idx, ref_rgb, ref_hits = cpu_baseline(world, cam, fuel)
