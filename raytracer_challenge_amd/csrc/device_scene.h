@@ -167,6 +167,8 @@ struct DScene {
   double abvh_frame[4];
   int32_t light_grid_n, light_grid_cell_off;  // the light grids' common n and light 0's cell_off (light l: + l * (6 n^2 + 1))
   int32_t light_grid_first;  // 0 or 1 + index in qgrids of light 0's light grid (= the b of the program's OP_BVH)
+  int32_t all_plain;         // 1: every material's pattern is a Plain colour (Pattern::color_at never walks a tree: kernels without the pattern stack)
+  int32_t no_glass_mirror;   // 1: no material both reflects and refracts (a hit never has two children: the one-kernel path stacks no pending ray)
   int32_t has_recs;          // 1: some op reads intersection records (pisect): analytic BVH, quirk scans, primitives outside the kernel arguments
   // Kernel-argument copy of a short traversal program (kernargs are read with scalar loads: the op fetch and the plane
   // records stop being per-lane vector loads on every ray's dependency chain).  Used when n_kops > 0: the whole program

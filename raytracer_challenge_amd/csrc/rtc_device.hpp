@@ -1373,7 +1373,10 @@ __device__ __forceinline__ Ray slot_ray(const DPixelMap& pm, const DCamera& cam,
 // (168 VGPRs, more spills); cache-resident scenes are 3-9 % slower there (profiles/r2_onekernel_occupancy.txt).
 // (LDS-resident scene tables, as in wf_ts, were measured on this kernel too — 256-thread blocks, two per CU — and lost 10 % on
 // config 3: its 22 KB of nodes and triangles already hit in L1, and a block retires with its slowest wave.)
-template <bool COUNT, int FEAT, bool KOPS, int WAVES = 0>
+// LEAN: for scenes whose patterns are all Plain colours and whose materials never both reflect and refract (DScene.all_plain,
+// no_glass_mirror: the teapot scenes) — no pattern-tree walk is compiled in and the pending-ray stack has one (unused) entry: 80 B of
+// scratch per lane instead of 1 648 (config 3 -3 %, config 4 -4 %: profiles/r3_partition_probe.txt).
+template <bool COUNT, int FEAT, bool KOPS, int WAVES = 0, bool LEAN = false>
 __global__ void __launch_bounds__(RTC_BLOCK, WAVES ? WAVES : ((FEAT >= 2 && RTC_WAVES_PER_SIMD < 2) ? 2 : RTC_WAVES_PER_SIMD)) rtc_trace_kernel(DScene S, DCamera cam, DPixelMap pm, int fuel0, double* __restrict__ rgb, double* __restrict__ hit_t,
                                                         int* __restrict__ hit_prim, int* __restrict__ hit_k, DStats* __restrict__ stats) {
   RTC_LDS_STACK(lds_stack);
@@ -1396,10 +1399,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, WAVES ? WAVES : ((FEAT >= 2 && RTC_
   if (have) {
     Ray ray = slot_ray(pm, cam, q);
 
-#ifndef RTC_PEND_MAX
-#define RTC_PEND_MAX RTC_MAX_FUEL
-#endif
-    Pending pend[RTC_PEND_MAX];
+    Pending pend[LEAN ? 1 : RTC_MAX_FUEL];
     int np = 0;
     double acc_r = 0.0, acc_g = 0.0, acc_b = 0.0;
     double weight = 1.0;
@@ -1463,12 +1463,8 @@ __global__ void __launch_bounds__(RTC_BLOCK, WAVES ? WAVES : ((FEAT >= 2 && RTC_
           double z = mi[8] * st.px + mi[9] * st.py + mi[10] * st.pz + mi[11] * 1.0;
           double w = mi[12] * st.px + mi[13] * st.py + mi[14] * st.pz + mi[15] * 1.0;
           const DPat& root = S.pats[S.mat_pattern[P.mat]];
-          if (root.tag == 1) { cr = root.color[0]; cg = root.color[1]; cb = root.color[2]; }
-#ifdef RTC_NO_PATTERNS
-          else { cr = cg = cb = 0.0; }
-#else
+          if (LEAN || root.tag == 1) { cr = root.color[0]; cg = root.color[1]; cb = root.color[2]; }
           else pattern_color(S, S.mat_pattern[P.mat], x, y, z, w, cr, cg, cb);
-#endif
         }
 
         DIAG_REGION(2);
@@ -1539,7 +1535,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, WAVES ? WAVES : ((FEAT >= 2 && RTC_
             }
           }
           // depth-first: the reflection ray (if any) is traced next; only a refraction ray that has to wait is stacked
-          if (do_refr && do_refl) {
+          if (!LEAN && do_refr && do_refl) {
             Pending& p = pend[np++];
             p.ox = st.ux; p.oy = st.uy; p.oz = st.uz; p.dx = tdx; p.dy = tdy; p.dz = tdz;
             p.weight = wt; p.fuel = fuel - 1; p.kind = 2;

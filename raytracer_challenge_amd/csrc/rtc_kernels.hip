@@ -1,9 +1,11 @@
 // rtc_kernels.hip — hand-written HIP for gfx950 (MI355X): the kernels of the hot path that do not depend on the scene's feature
 // level (wf_shade, wf_gather, the quantiser) and the host-callable launchers.  The ray kernels (rtc_trace_kernel, wf_ts) are
 // templates in rtc_device.hpp, instantiated per feature level by rtc_feat.hip (one translation unit per level, built in parallel).
+#include <cstdio>
 #include <cstdlib>
 
 #include "rtc_device.hpp"
+#include "rtc_sched.hpp"
 
 #define RTC_VARIANT_DECL(N)                                                                                                                                   \
   void rtc_launch_trace_v##N(bool count, int waves, unsigned grid, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, \
@@ -11,9 +13,12 @@
   void rtc_launch_wf_ts_v##N(bool count, unsigned grid, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, const DWave& W, int tl, \
                              int sl, unsigned n0, int slot, int fuel_left, double* hit_t, int* hit_prim, int* hit_k, DStats* stats);                         \
   int rtc_wf_ts_blocks_per_cu_v##N(unsigned lds_bytes);                                                                                                        \
+  int rtc_wf_tq_blocks_per_cu_v##N(unsigned lds_bytes);                                                                                                        \
+  bool rtc_launch_wf_tq_v##N(bool count, unsigned grid, unsigned lds_tables, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm,       \
+                             const DWave& W, int tl, int sl, unsigned n0, int slot, int fuel_left, double* hit_t, int* hit_prim, int* hit_k, DStats* stats);   \
   bool rtc_launch_wf_ts_lds_v##N(bool count, unsigned grid, unsigned lds_bytes, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm,   \
                                  const DWave& W, int tl, int sl, unsigned n0, int slot, int fuel_left, double* hit_t, int* hit_prim, int* hit_k, DStats* stats);
-RTC_VARIANT_DECL(0) RTC_VARIANT_DECL(1) RTC_VARIANT_DECL(2) RTC_VARIANT_DECL(3) RTC_VARIANT_DECL(4)
+RTC_VARIANT_DECL(0) RTC_VARIANT_DECL(1) RTC_VARIANT_DECL(2) RTC_VARIANT_DECL(3) RTC_VARIANT_DECL(4) RTC_VARIANT_DECL(5)
 #undef RTC_VARIANT_DECL
 #ifdef RTC_EMU
 // the CPU emulator (tests/cpu_emu) compiles everything as one translation unit
@@ -32,19 +37,24 @@ RTC_VARIANT_DECL(0) RTC_VARIANT_DECL(1) RTC_VARIANT_DECL(2) RTC_VARIANT_DECL(3) 
 #define RTC_VARIANT 4
 #include "rtc_feat.hip"
 #undef RTC_VARIANT
+#define RTC_VARIANT 5
+#include "rtc_feat.hip"
+#undef RTC_VARIANT
 #endif
 
 // kernel variant a scene needs (rtc_feat.hip): its feature level (rtc_device.hpp, visit_prim) and where its program lives
 static int rtc_variant(const DScene& S) {
   const int feat = S.has_csg ? 3 : (S.has_groups == 2 ? 2 : (S.has_groups ? 1 : 0));
   if (feat <= 1 && S.n_kops > 0) return feat;
+  if (feat == 2 && S.n_kops > 0) return 5;
   return feat <= 1 ? 2 : feat + 1;
 }
 
 #ifndef RTC_WF_SHADE_WAVES
 #define RTC_WF_SHADE_WAVES 4  // <= 128 VGPRs: two 512-thread blocks per CU, so one block's wait for its queue atomics is covered by the other
 #endif
-template <bool COUNT>
+// PAT = false: every pattern of the scene is a Plain colour (DScene.all_plain): no pattern-tree walk and none of its 672 B of scratch per lane.
+template <bool COUNT, bool PAT = true>
 __global__ void __launch_bounds__(RTC_WF_SHADE_BLOCK, RTC_WF_SHADE_WAVES) wf_shade(DScene S, DCamera cam, DPixelMap pm, DWave W, int level, unsigned n0, int fuel0, DStats* __restrict__ stats) {
   // per wave and class: its count, then its base index in the queue (double-buffered by iteration parity: no barrier needed before
   // the next iteration writes).  Classes keep like with like inside a block's span of the queues, so that most 64-item chunks of the
@@ -97,7 +107,7 @@ __global__ void __launch_bounds__(RTC_WF_SHADE_BLOCK, RTC_WF_SHADE_WAVES) wf_sha
       double z = mi[8] * st.px + mi[9] * st.py + mi[10] * st.pz + mi[11] * 1.0;
       double w = mi[12] * st.px + mi[13] * st.py + mi[14] * st.pz + mi[15] * 1.0;
       const DPat& root = S.pats[S.mat_pattern[P.mat]];
-      if (root.tag == 1) { cr = root.color[0]; cg = root.color[1]; cbl = root.color[2]; }
+      if (!PAT || root.tag == 1) { cr = root.color[0]; cg = root.color[1]; cbl = root.color[2]; }
       else pattern_color(S, S.mat_pattern[P.mat], x, y, z, w, cr, cg, cbl);
     }
     // reflected_color / refracted_color (src/world.rs:84-132), once per light in the reference -> factor L
@@ -221,6 +231,7 @@ static void launch_wf_ts(int v, bool count, unsigned grid, hipStream_t stream, c
     case 1: rtc_launch_wf_ts_v1(count, grid, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats); break;
     case 2: rtc_launch_wf_ts_v2(count, grid, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats); break;
     case 3: rtc_launch_wf_ts_v3(count, grid, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats); break;
+    case 5: rtc_launch_wf_ts_v5(count, grid, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats); break;
     default: rtc_launch_wf_ts_v4(count, grid, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats); break;
   }
 }
@@ -230,13 +241,14 @@ static void launch_wf_ts(int v, bool count, unsigned grid, hipStream_t stream, c
 // scene does not qualify (program not in the kernel arguments, tables + stacks beyond a CU's 160 KB) or RTC_WF_LDS=0.
 unsigned rtc_wavefront_lds_bytes(const DScene& S) {
   static const bool off = [] { const char* e = std::getenv("RTC_WF_LDS"); return e && e[0] == '0'; }();
-  if (off || rtc_variant(S) > 1) return 0;
+  if (off || (rtc_variant(S) > 1 && rtc_variant(S) != 5)) return 0;
   const unsigned long long need = rtc_lds_table_bytes(S) + (unsigned long long)RTC_LDS_BLOCK * (unsigned)S.bvh_stack * sizeof(int);
   return need <= 158ull * 1024 ? (unsigned)need : 0u;
 }
 static bool launch_wf_ts_lds(int v, bool count, unsigned grid, unsigned lds, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, const DWave& W, int tl,
                              int sl, unsigned n0, int slot, int fuel_left, double* hit_t, int* hit_prim, int* hit_k, DStats* stats) {
   if (v == 0) return rtc_launch_wf_ts_lds_v0(count, grid, lds, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
+  if (v == 5) return rtc_launch_wf_ts_lds_v5(count, grid, lds, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
   return rtc_launch_wf_ts_lds_v1(count, grid, lds, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
 }
 
@@ -250,6 +262,7 @@ unsigned rtc_wavefront_grid(const DScene& S, int n_cu) {
     case 1: per_cu = rtc_wf_ts_blocks_per_cu_v1(lds); break;
     case 2: per_cu = rtc_wf_ts_blocks_per_cu_v2(lds); break;
     case 3: per_cu = rtc_wf_ts_blocks_per_cu_v3(lds); break;
+    case 5: per_cu = rtc_wf_ts_blocks_per_cu_v5(lds); break;
     default: per_cu = rtc_wf_ts_blocks_per_cu_v4(lds); break;
   }
   return (unsigned)std::max(1, n_cu * per_cu);
@@ -276,8 +289,21 @@ void rtc_launch_wavefront(const DScene& S, const DCamera& cam, const DPixelMap& 
 #endif
   const dim3 sgrid(std::max(1u, shade_blocks)), sblock(RTC_WF_SHADE_BLOCK);
   // trace_0; shade_0; [shadow_0 + trace_1]; shade_1; ... [shadow_{fuel-1} + trace_fuel]; shade_fuel; shadow_fuel; sums
+  // RTC_WF_SCHED=1: the section-scheduler form of the traversal kernel (rtc_sched.hpp) where the scene's program fits it
+  static const bool sched_on = [] { const char* e = std::getenv("RTC_WF_SCHED"); return e && e[0] == '1'; }();
+  const bool sched = sched_on && v <= 1 && rtc_sched_fits(S) && W.cap < (1u << 29);
+#ifndef RTC_EMU
+  const unsigned tq_lds = sched && lds && (unsigned long long)lds + RTC_CQ_BYTES * (RTC_LDS_BLOCK / 64) <= 160ull * 1024 ? lds : 0u;
+  const unsigned tq_blocks = sched && !tq_lds ? (unsigned)std::max(1, (int)(shade_blocks / 2u) * (v == 0 ? rtc_wf_tq_blocks_per_cu_v0(rtc_stack_bytes(S)) : rtc_wf_tq_blocks_per_cu_v1(rtc_stack_bytes(S)))) : lds_blocks;
+#else
+  const unsigned tq_lds = 0u, tq_blocks = blocks;
+#endif
+  if (std::getenv("RTC_WF_SCHED_TRACE")) std::fprintf(stderr, "[rtc-wf] traversal kernel: %s (variant %d, LDS tables %u B)\n", sched ? "wf_tq" : "wf_ts", v, sched ? tq_lds : 0u);
   for (int level = 0; level <= fuel + 1; level++) {
     const int tl = level <= fuel ? level : -1, sl = level - 1;
+    if (sched && (v == 0 ? rtc_launch_wf_tq_v0(count, tq_blocks, tq_lds, stream, S, cam, pm, W, tl, sl, n0, level, fuel - level, hit_t, hit_prim, hit_k, stats)
+                         : rtc_launch_wf_tq_v1(count, tq_blocks, tq_lds, stream, S, cam, pm, W, tl, sl, n0, level, fuel - level, hit_t, hit_prim, hit_k, stats))) {
+    } else
 #ifndef RTC_EMU
     // (a device that refuses the LDS size — the opt-in is per device — runs the kernel that reads the tables from memory)
     if (!lds || !launch_wf_ts_lds(v, count, lds_blocks, lds, stream, S, cam, pm, W, tl, sl, n0, level, fuel - level, hit_t, hit_prim, hit_k, stats))
@@ -285,6 +311,7 @@ void rtc_launch_wavefront(const DScene& S, const DCamera& cam, const DPixelMap& 
     launch_wf_ts(v, count, blocks, stream, S, cam, pm, W, tl, sl, n0, level, fuel - level, hit_t, hit_prim, hit_k, stats);
     if (level <= fuel) {
       if (count) hipLaunchKernelGGL((wf_shade<true>), sgrid, sblock, 0, stream, S, cam, pm, W, level, n0, fuel, stats);
+      else if (S.all_plain) hipLaunchKernelGGL((wf_shade<false, false>), sgrid, sblock, 0, stream, S, cam, pm, W, level, n0, fuel, stats);
       else hipLaunchKernelGGL((wf_shade<false>), sgrid, sblock, 0, stream, S, cam, pm, W, level, n0, fuel, stats);
     }
   }
@@ -373,6 +400,7 @@ void rtc_launch_trace(const DScene& S, const DCamera& cam, const DPixelMap& pm, 
     case 1: rtc_launch_trace_v1(count, waves, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats); break;
     case 2: rtc_launch_trace_v2(count, waves, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats); break;
     case 3: rtc_launch_trace_v3(count, waves, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats); break;
+    case 5: rtc_launch_trace_v5(count, waves, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats); break;
     default: rtc_launch_trace_v4(count, waves, grid, stream, S, cam, pm, fuel, rgb, hit_t, hit_prim, hit_k, stats); break;
   }
 }

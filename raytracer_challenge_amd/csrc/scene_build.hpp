@@ -598,7 +598,10 @@ struct HostArrays {
   void fill_kernarg_program(DScene& d) const {
     d.n_kops = 0; d.n_kplanes = 0;
     if (std::getenv("RTC_NO_KOPS")) return;
-    if (ops.size() > RTC_KOPS || d.has_csg || d.has_groups == 2) return;
+    // (per-primitive gates — has_groups == 2 — do not change the op sequence: the gate is part of a primitive's own test.  Kernel
+    // variant 5 serves such programs; RTC_KOPS_GROUPS=0 sends them back to the program in memory.)
+    static const bool kops_groups = [] { const char* e = std::getenv("RTC_KOPS_GROUPS"); return !(e && e[0] == '0'); }();
+    if (ops.size() > RTC_KOPS || d.has_csg || (d.has_groups == 2 && !kops_groups)) return;
     for (const DOp& o : ops) if (o.op == OP_GROUP || o.op == OP_CSG || o.op == OP_CSG_END) return;
     int n_aux = 0;
     bool have_qgrid = false;
@@ -654,6 +657,10 @@ struct HostArrays {
     for (const DOp& o : ops) if (o.op == OP_BVH && o.b > 0) d.light_grid_first = o.b;
     d.light_grid_n = 0; d.light_grid_cell_off = 0;
     if (d.light_grid_first > 0) { d.light_grid_n = qgrids[(size_t)d.light_grid_first - 1].n; d.light_grid_cell_off = qgrids[(size_t)d.light_grid_first - 1].cell_off; }
+    d.all_plain = 1;
+    for (int32_t root : mat_pattern) if (root < 0 || (size_t)root >= pats.size() || pats[(size_t)root].tag != 1) d.all_plain = 0;
+    d.no_glass_mirror = 1;
+    for (size_t m = 0; m + 7 < mat.size(); m += 8) if (mat[m + 4] != 0.0 && mat[m + 5] != 0.0) d.no_glass_mirror = 0;
     d.has_recs = 0;
     for (size_t i = 0; i < ops.size(); i++) {
       const DOp& o = ops[i];
