@@ -196,11 +196,18 @@ def cpu_baseline(world, cam, fuel, target_seconds=30.0):  # the short probe over
     orc = oracle()
     nw = orc.build_world(world)
     total = cam.hsize * cam.vsize
-    probe = np.arange(0, total, max(1, total // 2048), dtype=np.uint64)[:2048]
     threads = cpu_threads()
-    _, _, st = orc.render_timed(nw, cam, fuel, probe, threads=threads)
-    per_px = max(st.seconds / len(probe), 1e-9)
-    n = int(min(total, max(4096, target_seconds / per_px)))
+    # probe: a strided sample grown until it has cost >= 1.5 s (the oracle's flat lists make a pixel of the 10^6-triangle scene cost
+    # seconds, a pixel of the analytic scene milliseconds), then the sample that fits target_seconds
+    n_probe, per_px = 64, None
+    while True:
+        probe = np.arange(0, total, max(1, total // n_probe), dtype=np.uint64)[:n_probe]
+        _, _, st = orc.render_timed(nw, cam, fuel, probe, threads=threads)
+        per_px = max(st.seconds / len(probe), 1e-9)
+        if st.seconds >= 1.5 or n_probe >= 4096:
+            break
+        n_probe *= 4
+    n = int(min(total, max(64, target_seconds / per_px)))
     stride = max(1, total // n)
     idx = np.arange(0, total, stride, dtype=np.uint64)
     rgb, hits, st = orc.render_timed(nw, cam, fuel, idx, threads=threads)
@@ -387,11 +394,11 @@ class Runtime:
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def measure(args, rtm, dist, workload, fuel, steps, warmup, F, rank, world_size, rehearse, want_pmc, want_cpu):
+def measure(args, rtm, dist, workload, fuel, steps, warmup, F, rank, world_size, rehearse, want_pmc, want_cpu, partition="bands"):
     """One workload on this process group.  Returns the dict of measurements (rank 0: complete; other ranks: partial)."""
     import numpy as np
     from raytracer_challenge_amd.device import algorithmic_bytes
-    from raytracer_challenge_amd.parallel import FrameGatherer
+    from raytracer_challenge_amd.parallel import FrameGatherer, FrameRoundGatherer
     torch, hip, dev = rtm.torch, rtm.backend, rtm.dev
     gather_dev = torch.device("cpu") if rehearse else dev
     cam, world, desc = make_workload(workload)
@@ -399,10 +406,20 @@ def measure(args, rtm, dist, workload, fuel, steps, warmup, F, rank, world_size,
     drs = [rtm.renderer(w, cam) for w in nws]
     nw, dr = nws[0], drs[0]
     H, V = cam.hsize, cam.vsize
-    fg = FrameGatherer(H, V, rank, world_size, gather_dev, dist, n_buffers=F, tile_device=dev)
+    # How N GPUs share the K frames of the timed region:
+    #   bands   every frame is cut into 8-row bands dealt round-robin over the ranks, one gather per frame (the north-star partition:
+    #           a frame's latency drops, but a ~2 ms frame's per-rank share is latency-bound: scripts/partition_probe.py predicts 3.8x at N = 8);
+    #   frames  whole frames round-robin over the ranks, a round of N frames delivered to rank 0 with one gather (same bytes per frame).
+    frames_mode = partition == "frames" and world_size > 1
+    if frames_mode:
+        fg = FrameRoundGatherer(H, V, rank, world_size, gather_dev, dist, n_buffers=F, tile_device=dev)
+        part, n_parts = 0, 1
+    else:
+        fg = FrameGatherer(H, V, rank, world_size, gather_dev, dist, n_buffers=F, tile_device=dev)
+        part, n_parts = rank, world_size
 
     def finish(i):
-        """Frame i: wait for its render (marker 0 of its renderer), then gather its tiles to rank 0 (RCCL) and de-interleave."""
+        """Step i: wait for its render (marker 0 of its renderer), then gather to rank 0 (RCCL) (and de-interleave)."""
         drs[i % F].wait(0)
         if world_size > 1:
             fg.gather(i % F)
@@ -410,13 +427,16 @@ def measure(args, rtm, dist, workload, fuel, steps, warmup, F, rank, world_size,
                 torch.cuda.current_stream().synchronize()  # tiles[i % F] is free again once the gather has consumed it
 
     def run_frames(k):
-        """k full frames, software-pipelined: up to F renders in flight; the gather of frame i - F runs behind them."""
-        for i in range(k):
+        """k full frames, software-pipelined: up to F renders in flight per GPU; the gather of step i - F runs behind them.
+        bands: a step is a frame (every rank renders its bands); frames: a step is a round of up to N frames, one per rank."""
+        n_steps = (k + world_size - 1) // world_size if frames_mode else k
+        for i in range(n_steps):
             if i >= F:
                 finish(i - F)
-            drs[i % F].render_rows_async(fuel, rank, world_size, fg.n_rows, fg.tiles[i % F], band_rows=fg.band_rows)
+            if not frames_mode or i * world_size + rank < k:   # (the last round of K frames may be short)
+                drs[i % F].render_rows_async(fuel, part, n_parts, fg.n_rows, fg.tiles[i % F], band_rows=fg.band_rows)
             drs[i % F].record(0)
-        for i in range(max(0, k - F), k):
+        for i in range(max(0, n_steps - F), n_steps):
             finish(i)
 
     def barrier():
@@ -427,14 +447,14 @@ def measure(args, rtm, dist, workload, fuel, steps, warmup, F, rank, world_size,
             d.sync()
 
     # untimed: counting variant -> unique rays + work counters of this rank's launch
-    cst = dr.render_rows(fuel, rank, world_size, fg.n_rows, fg.tiles[0], count=True, sync=True, band_rows=fg.band_rows)
+    cst = dr.render_rows(fuel, part, n_parts, fg.n_rows, fg.tiles[0], count=True, sync=True, band_rows=fg.band_rows)
     rays_local = torch.tensor([float(cst["unique_rays"])], dtype=torch.float64, device=gather_dev)
-    if world_size > 1:
+    if world_size > 1 and not frames_mode:
         dist.all_reduce(rays_local)
-    rays_total = float(rays_local.item())
+    rays_total = float(rays_local.item())   # unique rays of ONE whole frame
 
     # untimed: both device paths measured twice per renderer, the faster one kept
-    paths = [d.tune(fuel, rank, world_size, fg.n_rows, fg.tiles[j], band_rows=fg.band_rows) for j, d in enumerate(drs)]
+    paths = [d.tune(fuel, part, n_parts, fg.n_rows, fg.tiles[j], band_rows=fg.band_rows) for j, d in enumerate(drs)]
     path = paths[0]
     run_frames(warmup)
     for d in drs:
@@ -456,7 +476,7 @@ def measure(args, rtm, dist, workload, fuel, steps, warmup, F, rank, world_size,
     n_seq = max(5, min(50, steps))
     dr.record(2)
     for _ in range(n_seq):
-        dr.render_rows_async(fuel, rank, world_size, fg.n_rows, fg.tiles[0], band_rows=fg.band_rows)
+        dr.render_rows_async(fuel, part, n_parts, fg.n_rows, fg.tiles[0], band_rows=fg.band_rows)
     dr.record(3)
     dr.sync()
     dr.check()
@@ -464,7 +484,8 @@ def measure(args, rtm, dist, workload, fuel, steps, warmup, F, rank, world_size,
     timed_tile = fg.tiles[0].clone()
 
     res = {"workload": workload, "desc": desc, "H": H, "V": V, "fuel": fuel, "steps": steps, "warmup": warmup, "elapsed": elapsed, "rays_total": rays_total,
-           "seq_ms": seq_ms, "path": path, "counters": cst, "n_lights": nw.n_lights, "primitives": nw.primitive_count, "info": dr.info(), "F": F}
+           "seq_ms": seq_ms, "path": path, "counters": cst, "n_lights": nw.n_lights, "primitives": nw.primitive_count, "info": dr.info(), "F": F,
+           "partition": "frames" if frames_mode else "bands"}
     if rank != 0 or args.pmc_child:
         return res
     alg = algorithmic_bytes(cst, path["path"], nw.primitive_count, lds_tables=dr.info().get("wavefront_lds_bytes_per_block", 0) > 0)
@@ -507,11 +528,17 @@ def measure(args, rtm, dist, workload, fuel, steps, warmup, F, rank, world_size,
         # N ranks: the frame rank 0 gathered (every rank's interleaved rows, de-interleaved) against the same frame rendered by rank 0's
         # device alone through rtc_render — the frame the N = 1 line checks against the oracle
         single, _ = hip.render(nw, cam, fuel, want_hits=False)
-        gathered = fg.image.detach().cpu().numpy().reshape(-1, 3)
-        res["parity"] = {"pixels": int(H * V), "gathered_frame_equals_single_gpu_frame": bool(np.array_equal(gathered, single)),
-                         "max_abs_drgb_vs_single_gpu_frame": float(np.abs(gathered - single).max()),
-                         "checked": "rank 0's gathered, de-interleaved frame of the timed path against rtc_render of the whole frame on rank 0's device; "
-                                    "the oracle comparison of that frame is the parity block of the N = 1 line"}
+        if frames_mode:   # every rank's last delivered frame against rank 0's own render of the frame
+            got = fg.frames.detach().cpu().numpy().reshape(world_size, -1, 3)
+            same = all(bool(np.array_equal(got[r], single)) for r in range(world_size))
+            worst = float(max(np.abs(got[r] - single).max() for r in range(world_size)))
+        else:
+            gathered = fg.image.detach().cpu().numpy().reshape(-1, 3)
+            same, worst = bool(np.array_equal(gathered, single)), float(np.abs(gathered - single).max())
+        res["parity"] = {"pixels": int(H * V), "gathered_frame_equals_single_gpu_frame": same,
+                         "max_abs_drgb_vs_single_gpu_frame": worst,
+                         "checked": "the frame(s) rank 0 gathered in the timed path (bands: de-interleaved; frames: the last frame every rank delivered) against "
+                                    "rtc_render of the whole frame on rank 0's device; the oracle comparison of that frame is the parity block of the N = 1 line"}
     if world_size == 1:
         # PCIe-inclusive figures: Image::par_render returns host pixels (src/image.rs:76-80).  rtc_render / rtc_render_rgb8 into
         # a FRESH destination every call (what `-> Image` means: a new Vec whose pages do not exist yet), into a reused one, and
@@ -538,6 +565,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC child passes (roofline.traffic = null)")
     ap.add_argument("--extra-workloads", default="config3", help="comma list of further workloads measured in full after the headline one, at N=1")
+    ap.add_argument("--partition", default="auto", choices=["auto", "bands", "frames"],
+                    help="N > 1: bands = every frame cut into 8-row bands over the ranks (one gather per frame); frames = whole frames round-robin "
+                         "over the ranks (one gather per round of N frames); auto = frames when at least 2 N frames are timed, else bands")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--one-shot-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-one-shot", action="store_true", help="skip the one-shot (fresh process, one render) measurements")
@@ -583,8 +613,18 @@ def main():
         return
 
     F = max(1, args.inflight)
+    partition = args.partition
+    if partition == "auto":
+        partition = "frames" if world_size > 1 and args.steps >= 2 * world_size else "bands"
+    if partition == "frames" and args.steps < world_size:
+        partition = "bands"   # fewer frames than GPUs: nothing to deal out
     m = measure(args, rtm, dist, args.workload, args.fuel, args.steps, args.warmup, F, rank, world_size, rehearse,
-                want_pmc=not args.no_pmc, want_cpu=not args.no_cpu_baseline)
+                want_pmc=not args.no_pmc, want_cpu=not args.no_cpu_baseline, partition=partition)
+    band = None
+    if world_size > 1 and m["partition"] == "frames":
+        # the north-star partition beside it: every frame cut into bands over the ranks (what a single frame's latency gets from N GPUs)
+        band = measure(args, rtm, dist, args.workload, args.fuel, max(2, min(args.steps, 60)), min(args.warmup, 3), F, rank, world_size, rehearse,
+                       want_pmc=False, want_cpu=False, partition="bands")
     if rank == 0:
         H, V = m["H"], m["V"]
         out = {
@@ -596,7 +636,9 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic" if not standin else "synthetic; CPU STAND-IN REHEARSAL of the bench plumbing (kernel source emulated on the CPU): not a measurement",
             "config": {"workload": m["desc"], "hsize": H, "vsize": V, "fuel": m["fuel"], "lights": m["n_lights"], "primitives": m["primitives"],
-                       "partition": "8-row bands dealt round-robin by rank, RCCL gather to rank 0" if world_size > 1 else "single GPU",
+                       "partition": ("single GPU" if world_size == 1 else
+                                     "frames: whole frames round-robin over the ranks, F in flight per GPU, a round of N frames gathered to rank 0 over RCCL (same bytes per frame as bands)"
+                                     if m["partition"] == "frames" else "bands: every frame in 8-row bands dealt round-robin by rank, RCCL gather to rank 0"),
                        "frames_in_flight": F, "process_group": {"world_size": world_size, "backend": backend_name},
                        "unique_rays_per_frame": m["rays_total"], "rays_per_pixel": m["rays_total"] / (H * V)},
             "roofline": m["roofline"],
@@ -605,6 +647,11 @@ def main():
         for k in ("valu", "parity", "cpu_baseline", "ms_per_step_incl_d2h", "host_pixels"):
             if k in m:
                 out[k] = m[k]
+        if band is not None:
+            out["band_partition"] = {"value": band["rays_total"] * band["steps"] / band["elapsed"] / 1e6, "unit": "Mrays/s", "steps": band["steps"],
+                                     "ms_per_step": band["elapsed"] / band["steps"] * 1e3, "parity": band.get("parity"),
+                                     "note": "the same job with every frame cut into 8-row bands over the ranks (one gather per frame): what ONE frame's latency gets "
+                                             "from N GPUs; its per-rank share is latency-bound (DESIGN.md section 6)"}
         if world_size == 1 and not args.no_one_shot and not standin:
             out["one_shot"] = one_shot_measure()
         if world_size == 1:

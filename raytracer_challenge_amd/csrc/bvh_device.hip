@@ -23,31 +23,36 @@ namespace {
 
 struct DevBox { double lo[3], hi[3]; };
 
-__device__ __forceinline__ unsigned long long spread21(unsigned long long v) {  // 21 bits -> every third bit
-  v &= 0x1fffffull;
-  v = (v | (v << 32)) & 0x1f00000000ffffull;
-  v = (v | (v << 16)) & 0x1f0000ff0000ffull;
-  v = (v | (v << 8)) & 0x100f00f00f00f00full;
-  v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
-  v = (v | (v << 2)) & 0x1249249249249249ull;
-  return v;
-}
-
+// Sort key of an item: its centroid's cell in a recursive bisection of the items' bounds that always halves the LONGEST side of
+// the current cell (round 3).  A plain Morton code gives every axis every third bit whatever the bounds' shape; for a flat mesh
+// (config 5: a heightfield 400 x 400 units wide and a few units high) a third of the radix tree's levels then split along the
+// short axis, where nearly every triangle straddles the plane — children that overlap almost completely (config 5 rendered at
+// 16.4 ms per frame against the host SAH tree's 10.9).  The bisection order (63 axis choices, two bits each in seq_lo / seq_hi,
+// most significant key bit first) and the bits per axis come from the host (extent_bisection below).
 __global__ void __launch_bounds__(256) morton_kernel(const DevBox* __restrict__ items, uint32_t n, double lox, double loy, double loz, double sx, double sy, double sz,
+                                                     unsigned bx, unsigned by, unsigned bz, unsigned long long seq_lo, unsigned long long seq_hi,
                                                      unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const DevBox b = items[i];
   const double c[3] = {0.5 * (b.lo[0] + b.hi[0]), 0.5 * (b.lo[1] + b.hi[1]), 0.5 * (b.lo[2] + b.hi[2])};
   const double lo[3] = {lox, loy, loz}, s[3] = {sx, sy, sz};
+  unsigned rem[3] = {bx, by, bz};
   unsigned long long q[3];
   for (int a = 0; a < 3; a++) {
-    double t = (c[a] - lo[a]) * s[a];          // [0, 2^21)
+    double t = (c[a] - lo[a]) * s[a];          // [0, 2^bits)
+    const double top = (double)((1ull << rem[a]) - 1ull);
     if (!(t >= 0.0)) t = 0.0;                  // NaN / below
-    if (t > 2097151.0) t = 2097151.0;
+    if (t > top) t = top;
     q[a] = (unsigned long long)t;
   }
-  keys[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+  unsigned long long key = 0ull;
+  for (int k = 0; k < 63; k++) {
+    const unsigned a = (unsigned)((k < 32 ? seq_lo >> (2 * k) : seq_hi >> (2 * (k - 32))) & 3ull);
+    rem[a]--;
+    key = (key << 1) | ((q[a] >> rem[a]) & 1ull);
+  }
+  keys[i] = key;
   vals[i] = i;
 }
 
@@ -181,6 +186,27 @@ __global__ void __launch_bounds__(256) emit_kernel(const DevBox* __restrict__ it
   out[newidx[i]] = N;
 }
 
+// The 63 bisections of the key (see morton_kernel): always the longest side of the current cell; an axis without extent gets no bit.
+struct Bisection { unsigned bits[3]; unsigned long long seq_lo, seq_hi; };
+Bisection extent_bisection(const double ext[3]) {
+  Bisection B = {{0, 0, 0}, 0ull, 0ull};
+  double cell[3];
+  for (int a = 0; a < 3; a++) cell[a] = ext[a] > 0.0 && std::isfinite(ext[a]) ? ext[a] : 0.0;
+  for (int k = 0; k < 63; k++) {
+    int a = 0;
+    for (int c = 1; c < 3; c++) if (cell[c] > cell[a]) a = c;
+    if (B.bits[a] >= 30) {  // (a side 2^30 times the others: give the bit to the next longest)
+      int best = -1;
+      for (int c = 0; c < 3; c++) if (B.bits[c] < 30 && (best < 0 || cell[c] > cell[best])) best = c;
+      a = best;
+    }
+    B.bits[a]++;
+    cell[a] *= 0.5;
+    if (k < 32) B.seq_lo |= (unsigned long long)a << (2 * k); else B.seq_hi |= (unsigned long long)a << (2 * (k - 32));
+  }
+  return B;
+}
+
 struct Scratch {
   std::vector<void*> p;
   ~Scratch() { for (void* q : p) (void)hipFree(q); }
@@ -207,13 +233,15 @@ int32_t rtc_bvh_build_device(const std::vector<bvh::Item>& items, std::vector<DB
     bvh::Builder::grow(all, it);
     for (int a = 0; a < 3; a++) { const double c = 0.5 * (it.lo[a] + it.hi[a]); cb.lo[a] = std::min(cb.lo[a], c); cb.hi[a] = std::max(cb.hi[a], c); }
   }
-  double center[3], rad = 0.0, scale[3];
+  double center[3], rad = 0.0, scale[3], ext3[3];
+  for (int a = 0; a < 3; a++) ext3[a] = cb.hi[a] - cb.lo[a];
+  const Bisection bis = extent_bisection(ext3);
   for (int a = 0; a < 3; a++) {
     center[a] = 0.5 * (all.lo[a] + all.hi[a]);
     if (!std::isfinite(center[a])) return -1;  // unbounded items: the host builder copes
     rad = std::max(rad, std::max(std::fabs(all.hi[a] - center[a]), std::fabs(all.lo[a] - center[a])));
     const double ext = cb.hi[a] - cb.lo[a];
-    scale[a] = ext > 0.0 && std::isfinite(ext) ? 2097152.0 / ext * (1.0 - 1e-12) : 0.0;
+    scale[a] = ext > 0.0 && std::isfinite(ext) ? (double)(1ull << bis.bits[a]) / ext * (1.0 - 1e-12) : 0.0;
   }
   Scratch S;
   DevBox *d_items = nullptr, *d_box = nullptr;
@@ -230,7 +258,8 @@ int32_t rtc_bvh_build_device(const std::vector<bvh::Item>& items, std::vector<DB
   }
   if (hipMemcpy(d_items, items.data(), n * sizeof(DevBox), hipMemcpyHostToDevice) != hipSuccess) return -1;
   const unsigned blocks = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(morton_kernel, dim3(blocks), dim3(256), 0, 0, d_items, (uint32_t)n, cb.lo[0], cb.lo[1], cb.lo[2], scale[0], scale[1], scale[2], d_k0, d_v0);
+  hipLaunchKernelGGL(morton_kernel, dim3(blocks), dim3(256), 0, 0, d_items, (uint32_t)n, cb.lo[0], cb.lo[1], cb.lo[2], scale[0], scale[1], scale[2], bis.bits[0], bis.bits[1], bis.bits[2],
+                     bis.seq_lo, bis.seq_hi, d_k0, d_v0);
   size_t tmp_bytes = 0;
   if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (int)n, 0, 63) != hipSuccess) return -1;
   unsigned char* d_tmp = nullptr;

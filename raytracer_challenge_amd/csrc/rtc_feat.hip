@@ -16,9 +16,6 @@
 #ifndef RTC_EMU
 #include <atomic>
 #endif
-#if RTC_VARIANT <= 1
-#include "rtc_sched.hpp"
-#endif
 
 #ifndef RTC_VARIANT
 #error "compile with -DRTC_VARIANT=0..4"
@@ -79,58 +76,6 @@ void RTC_CAT(rtc_launch_wf_ts_v, RTC_VARIANT)(bool count, unsigned grid, hipStre
                                               unsigned n0, int slot, int fuel_left, double* hit_t, int* hit_prim, int* hit_k, DStats* stats) {
   if (count) hipLaunchKernelGGL((wf_ts<true, RTC_V_FEAT, RTC_V_KOPS>), dim3(grid), dim3(RTC_BLOCK), rtc_stack_bytes(S), stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
   else hipLaunchKernelGGL((wf_ts<false, RTC_V_FEAT, RTC_V_KOPS>), dim3(grid), dim3(RTC_BLOCK), rtc_stack_bytes(S), stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
-}
-
-// wf_tq (rtc_sched.hpp): the section-scheduler form of the traversal kernel, kernel-argument programs only.  lds_tables = dynamic LDS of the
-// scene tables + stacks (0: tables in memory, one-wave blocks); the container lists come on top.  false: not launched (wrong variant / refused).
-bool RTC_CAT(rtc_launch_wf_tq_v, RTC_VARIANT)(bool count, unsigned grid, unsigned lds_tables, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm,
-                                              const DWave& W, int tl, int sl, unsigned n0, int slot, int fuel_left, double* hit_t, int* hit_prim, int* hit_k, DStats* stats) {
-#if RTC_VARIANT <= 1
-#ifndef RTC_EMU
-  if (lds_tables) {
-    static std::atomic<unsigned long long> raised{0ull}, refused{0ull};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-    const unsigned long long bit = 1ull << dev;
-    if (refused.load(std::memory_order_acquire) & bit) return false;
-    if (!(raised.load(std::memory_order_acquire) & bit)) {
-      hipFuncAttributes fa;
-      const int st = hipFuncGetAttributes(&fa, (const void*)wf_tq<false, RTC_V_FEAT, true>) == hipSuccess ? (int)fa.sharedSizeBytes : 0;
-      const hipError_t e1 = hipFuncSetAttribute((const void*)wf_tq<true, RTC_V_FEAT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - st);
-      const hipError_t e2 = hipFuncSetAttribute((const void*)wf_tq<false, RTC_V_FEAT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - st);
-      if (e1 != hipSuccess || e2 != hipSuccess) {
-        (void)hipGetLastError();
-        refused.fetch_or(bit, std::memory_order_acq_rel);
-        return false;
-      }
-      raised.fetch_or(bit, std::memory_order_acq_rel);
-    }
-    const unsigned lds = lds_tables + RTC_CQ_BYTES * (RTC_LDS_BLOCK / 64);
-    if (count) hipLaunchKernelGGL((wf_tq<true, RTC_V_FEAT, true>), dim3(grid), dim3(RTC_LDS_BLOCK), lds, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
-    else hipLaunchKernelGGL((wf_tq<false, RTC_V_FEAT, true>), dim3(grid), dim3(RTC_LDS_BLOCK), lds, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
-    return true;
-  }
-#endif
-  (void)lds_tables;
-  const unsigned lds = rtc_stack_bytes(S) + RTC_CQ_BYTES;
-  if (count) hipLaunchKernelGGL((wf_tq<true, RTC_V_FEAT, false>), dim3(grid), dim3(RTC_BLOCK), lds, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
-  else hipLaunchKernelGGL((wf_tq<false, RTC_V_FEAT, false>), dim3(grid), dim3(RTC_BLOCK), lds, stream, S, cam, pm, W, tl, sl, n0, slot, fuel_left, hit_t, hit_prim, hit_k, stats);
-  return true;
-#else
-  (void)count; (void)grid; (void)lds_tables; (void)stream; (void)S; (void)cam; (void)pm; (void)W; (void)tl; (void)sl; (void)n0; (void)slot; (void)fuel_left;
-  (void)hit_t; (void)hit_prim; (void)hit_k; (void)stats;
-  return false;
-#endif
-}
-int RTC_CAT(rtc_wf_tq_blocks_per_cu_v, RTC_VARIANT)(unsigned lds_bytes) {
-#if RTC_VARIANT <= 1 && !defined(RTC_EMU)
-  int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wf_tq<false, RTC_V_FEAT, false>, RTC_BLOCK, lds_bytes + RTC_CQ_BYTES) != hipSuccess || nb <= 0) nb = 8;
-  return nb;
-#else
-  (void)lds_bytes;
-  return 0;
-#endif
 }
 
 #ifndef RTC_EMU

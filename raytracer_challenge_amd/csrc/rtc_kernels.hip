@@ -5,7 +5,6 @@
 #include <cstdlib>
 
 #include "rtc_device.hpp"
-#include "rtc_sched.hpp"
 
 #define RTC_VARIANT_DECL(N)                                                                                                                                   \
   void rtc_launch_trace_v##N(bool count, int waves, unsigned grid, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, int fuel, double* rgb, \
@@ -13,9 +12,6 @@
   void rtc_launch_wf_ts_v##N(bool count, unsigned grid, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm, const DWave& W, int tl, \
                              int sl, unsigned n0, int slot, int fuel_left, double* hit_t, int* hit_prim, int* hit_k, DStats* stats);                         \
   int rtc_wf_ts_blocks_per_cu_v##N(unsigned lds_bytes);                                                                                                        \
-  int rtc_wf_tq_blocks_per_cu_v##N(unsigned lds_bytes);                                                                                                        \
-  bool rtc_launch_wf_tq_v##N(bool count, unsigned grid, unsigned lds_tables, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm,       \
-                             const DWave& W, int tl, int sl, unsigned n0, int slot, int fuel_left, double* hit_t, int* hit_prim, int* hit_k, DStats* stats);   \
   bool rtc_launch_wf_ts_lds_v##N(bool count, unsigned grid, unsigned lds_bytes, hipStream_t stream, const DScene& S, const DCamera& cam, const DPixelMap& pm,   \
                                  const DWave& W, int tl, int sl, unsigned n0, int slot, int fuel_left, double* hit_t, int* hit_prim, int* hit_k, DStats* stats);
 RTC_VARIANT_DECL(0) RTC_VARIANT_DECL(1) RTC_VARIANT_DECL(2) RTC_VARIANT_DECL(3) RTC_VARIANT_DECL(4) RTC_VARIANT_DECL(5)
@@ -289,21 +285,8 @@ void rtc_launch_wavefront(const DScene& S, const DCamera& cam, const DPixelMap& 
 #endif
   const dim3 sgrid(std::max(1u, shade_blocks)), sblock(RTC_WF_SHADE_BLOCK);
   // trace_0; shade_0; [shadow_0 + trace_1]; shade_1; ... [shadow_{fuel-1} + trace_fuel]; shade_fuel; shadow_fuel; sums
-  // RTC_WF_SCHED=1: the section-scheduler form of the traversal kernel (rtc_sched.hpp) where the scene's program fits it
-  static const bool sched_on = [] { const char* e = std::getenv("RTC_WF_SCHED"); return e && e[0] == '1'; }();
-  const bool sched = sched_on && v <= 1 && rtc_sched_fits(S) && W.cap < (1u << 29);
-#ifndef RTC_EMU
-  const unsigned tq_lds = sched && lds && (unsigned long long)lds + RTC_CQ_BYTES * (RTC_LDS_BLOCK / 64) <= 160ull * 1024 ? lds : 0u;
-  const unsigned tq_blocks = sched && !tq_lds ? (unsigned)std::max(1, (int)(shade_blocks / 2u) * (v == 0 ? rtc_wf_tq_blocks_per_cu_v0(rtc_stack_bytes(S)) : rtc_wf_tq_blocks_per_cu_v1(rtc_stack_bytes(S)))) : lds_blocks;
-#else
-  const unsigned tq_lds = 0u, tq_blocks = blocks;
-#endif
-  if (std::getenv("RTC_WF_SCHED_TRACE")) std::fprintf(stderr, "[rtc-wf] traversal kernel: %s (variant %d, LDS tables %u B)\n", sched ? "wf_tq" : "wf_ts", v, sched ? tq_lds : 0u);
   for (int level = 0; level <= fuel + 1; level++) {
     const int tl = level <= fuel ? level : -1, sl = level - 1;
-    if (sched && (v == 0 ? rtc_launch_wf_tq_v0(count, tq_blocks, tq_lds, stream, S, cam, pm, W, tl, sl, n0, level, fuel - level, hit_t, hit_prim, hit_k, stats)
-                         : rtc_launch_wf_tq_v1(count, tq_blocks, tq_lds, stream, S, cam, pm, W, tl, sl, n0, level, fuel - level, hit_t, hit_prim, hit_k, stats))) {
-    } else
 #ifndef RTC_EMU
     // (a device that refuses the LDS size — the opt-in is per device — runs the kernel that reads the tables from memory)
     if (!lds || !launch_wf_ts_lds(v, count, lds_blocks, lds, stream, S, cam, pm, W, tl, sl, n0, level, fuel - level, hit_t, hit_prim, hit_k, stats))

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
@@ -458,12 +459,17 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
   HIP_OK(hipSetDevice(device));
   rtb::HostArrays H;
   std::string err;
-  // RTC_DEVICE_BVH=1: mesh accelerators are built on the device (LBVH, bvh_device.hip) instead of the host's binned SAH: same
-  // pixels (the accelerator is results-neutral), faster build, slower trees
+  // Mesh accelerators of at least 100 000 triangles are built on the device (LBVH over extent-aware bisection keys, bvh_device.hip)
+  // instead of by the host's binned SAH: same pixels (the accelerator is results-neutral), a quarter of the build time, frames
+  // within 8 % of the SAH tree's (config 5: 11.8 vs 10.9 ms; profiles/r3_device_bvh_build.txt).  RTC_DEVICE_BVH=0: always the host
+  // build; =1: the device build from 4 096 triangles up (RTC_DEVICE_BVH_MIN overrides either threshold).
   const char* dbe = std::getenv("RTC_DEVICE_BVH");
-  const bool device_bvh = dbe && dbe[0] == '1';
-  int rc = rtb::build_arrays(*desc, &H, &err, device_bvh ? rtc_bvh_build_device : nullptr);
+  const bool device_bvh = !(dbe && dbe[0] == '0');
+  const size_t device_min = (dbe && dbe[0] == '1') ? 4096 : 100000;
+  int rc = rtb::build_arrays(*desc, &H, &err, device_bvh ? rtc_bvh_build_device : nullptr, device_min);
   if (rc != RTC_OK) return rtc_fail(rc, err);
+  const bool timing = std::getenv("RTC_TIMING") != nullptr;
+  const auto t_up0 = std::chrono::steady_clock::now();
 
   // (every early return below releases what was created so far: streams, events, uploaded tables)
   struct SceneDeleter { void operator()(rtc_scene* p) const { rtc_scene_destroy(p); } };
@@ -542,6 +548,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     ok = verify("ops", d.ops, H.ops.data(), H.ops.size() * sizeof(DOp)) && ok;
     std::fprintf(stderr, "[rtc] upload verify: %s; n_items=%zu n_qcell=%zu n_prims=%zu\n", ok ? "ok" : "MISMATCH", H.items.size(), H.qcell.size(), H.prims.size());
   }
+  if (timing) std::fprintf(stderr, "[rtc-timing] %-28s %.3f s (%.1f MB)\n", "upload", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_up0).count(), (double)s->bytes / 1e6);
   HIP_OK(hipMalloc((void**)&s->d_stats, sizeof(DStats)));
   HIP_OK(hipMemset(s->d_stats, 0, sizeof(DStats)));
   {

@@ -1,6 +1,9 @@
 // rtw_capi.cpp — include/rtw.h for the product: C handles over the host mirror (host_scene.hpp).  A world is
 // flattened once (first render after the last edit), uploaded through rtc_scene_create, and every render goes
 // to the HIP kernels through the rtc.h entry points.  Nothing here can compute a pixel on the CPU.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <memory>
@@ -37,10 +40,12 @@ static Mat to_mat(const rtw_material* m) {
 
 static int ensure_scene(rtw_world* w) {
   if (w->scene) return 0;
+  const auto t0 = std::chrono::steady_clock::now();
   Flat f;
   Flattener fl(f);
   if (!fl.run(w->w)) return fail("flatten: " + f.error);
   rtc_scene_desc d = f.desc();
+  if (std::getenv("RTC_TIMING")) std::fprintf(stderr, "[rtc-timing] %-28s %.3f s\n", "flatten (host mirror -> desc)", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   int rc = rtc_scene_create(&d, w->device, &w->scene);
   if (rc != RTC_OK) return fail(std::string("rtc_scene_create: ") + rtc_last_error());
   return 0;

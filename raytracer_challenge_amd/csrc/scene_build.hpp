@@ -672,7 +672,7 @@ struct HostArrays {
 };
 
 // desc -> arrays.  Returns an RTC_* status; message in *err.
-inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err, bvh::DeviceBuildFn device_build = nullptr) {
+inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err, bvh::DeviceBuildFn device_build = nullptr, size_t device_build_min = 4096) {
   int rc = validate(D, err);
   if (rc != RTC_OK) return rc;
   if (D.n_lights > 64) { *err = "more than 64 lights"; return RTC_ERR_INVALID; }
@@ -687,6 +687,7 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
   lap("validate");
   ProgramBuilder pb{D};
   pb.device_build = device_build;
+  pb.device_build_min = device_build_min;
   if (const char* e = std::getenv("RTC_CUBE_PAD")) pb.cube_pad = std::max(0.0, std::atof(e));
   for (uint32_t i = 0; i < D.n_prims && pb.cube_pad > 0.0; i++) {  // the reach argument needs |t| EPSILON s << |t| |d| (s = the cube's scale)
     if (D.prims[i].geometry != RTC_CUBE) continue;

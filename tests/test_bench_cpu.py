@@ -31,6 +31,13 @@ def test_bench_gpus_2_launches_its_own_ranks():
     assert j["config"]["process_group"] == {"world_size": 2, "backend": "gloo"}
     assert j["config"]["frames_in_flight"] == 3 and j["scaling"] == "strong" and j["value"] > 0
     assert "STAND-IN" in j["data"]
+    assert j["config"]["partition"].startswith("bands") and "band_partition" not in j     # 3 frames < 2 N: every frame cut into bands
+    # enough frames queued (>= 2 N): whole frames round-robin over the ranks, the band partition measured beside it
+    f = run_bench("--gpus", "2", "--workload", "smoke", "--steps", "5", "--warmup", "1", "--no-cpu-baseline")
+    assert f["config"]["partition"].startswith("frames") and f["steps"] == 5 and f["n_gpus"] == 2
+    assert f["parity"]["gathered_frame_equals_single_gpu_frame"] is True
+    assert f["band_partition"]["parity"]["gathered_frame_equals_single_gpu_frame"] is True and f["band_partition"]["value"] > 0
+    assert f["config"]["unique_rays_per_frame"] == j["config"]["unique_rays_per_frame"]
     one = run_bench("--gpus", "1", "--workload", "smoke", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--extra-workloads", "")
     # same frame, same unique rays, whatever the partition
     assert one["config"]["unique_rays_per_frame"] == j["config"]["unique_rays_per_frame"]

@@ -53,3 +53,13 @@ def test_device_build_of_a_million_triangles(hip, tmp_path, monkeypatch):
         out[flag] = hip.render(nw, cam, 8, idx)
         assert (built_on_device(hip, nw) > 0) == (flag == "1")
     assert np.array_equal(out["0"][1], out["1"][1]) and np.array_equal(out["0"][0], out["1"][0])
+    # the default (RTC_DEVICE_BVH unset): a mesh of >= 100 000 triangles is built on the device, a small one on the host
+    monkeypatch.delenv("RTC_DEVICE_BVH")
+    nw = hip.build_world(world)
+    got = hip.render(nw, cam, 8, idx)
+    assert built_on_device(hip, nw) > 0
+    assert np.array_equal(got[1], out["0"][1]) and np.array_equal(got[0], out["0"][0])
+    cam2, world2 = scenes.chapter15_teapot("teapot_high.obj", 64, 36)
+    nw2 = hip.build_world(world2)
+    hip.render(nw2, cam2, 1)
+    assert built_on_device(hip, nw2) == 0
