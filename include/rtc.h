@@ -27,9 +27,10 @@ typedef struct rtc_scene rtc_scene;
 enum {
   RTC_OK = 0,
   RTC_ERR_INVALID = 1,     /* malformed description (index out of range, pattern too deep, ...)        */
-  RTC_ERR_UNSUPPORTED = 2, /* valid in the reference, beyond a device limit: CSG groups nested deeper than 8;
-                              a launch whose CSG intersection slab would exceed RTC_CSG_MAX_BYTES (16 GiB: a
-                              subtree with more than 32 possible intersections gets that many rows per thread) */
+  RTC_ERR_UNSUPPORTED = 2, /* valid in the reference, beyond a device limit: CSG groups nested deeper than 32; a
+                              pattern with more than RTC_MAX_PATTERN_DEPTH colour frames on one path (below); a launch
+                              whose CSG intersection slab would exceed RTC_CSG_MAX_BYTES (16 GiB: a subtree with more
+                              than 32 possible intersections gets that many rows per thread) */
   RTC_ERR_DEVICE = 3,      /* HIP failure / no device                                                   */
   RTC_ERR_NAN = 4          /* a NaN intersection t was produced; the reference panics when it sorts it
                               (src/intersection.rs:124)                                                 */
@@ -69,6 +70,9 @@ enum { RTC_PAT_DEBUG = 0, RTC_PAT_PLAIN = 1, RTC_PAT_JITTER = 2, RTC_PAT_MIXTURE
 enum { RTC_JITTER_COLOR = 0, RTC_JITTER_POINT = 1 };
 enum { RTC_MIX_BLEND = 0, RTC_MIX_CHECKERS = 1, RTC_MIX_RING_GRADIENT = 2, RTC_MIX_RING = 3, RTC_MIX_GRADIENT = 4, RTC_MIX_STRIPES = 5 };
 enum { RTC_NOISE_SIMPLEX = 0, RTC_NOISE_FRACTAL = 1 };
+/* Pattern trees may be of any depth (the reference's Box tree is unbounded); the device's walk keeps a frame only at nodes that
+ * need both children's colours (Blend, RingGradient, Gradient) or post-process a child's colour (colour jitter): at most this many
+ * of THOSE on one root-to-leaf path, else RTC_ERR_UNSUPPORTED.  Checkers, rings, stripes and point jitters nest freely. */
 #define RTC_MAX_PATTERN_DEPTH 8
 typedef struct rtc_pattern_node {
   int32_t tag;        /* RTC_PAT_* */

@@ -91,7 +91,7 @@ struct DCsg {
 #define RTC_CSG_MAX_HITS 32   // intersections of one top-level CSG subtree that fit the per-lane buffer; a scene whose subtrees can
                               // produce more (DScene.csg_max_hits, computed at scene creation) gets a slab in device memory with
                               // csg_max_hits entries per lane of the launch (the reference's lists are unbounded, src/shape.rs:248-269)
-#define RTC_CSG_MAX_DEPTH 8
+#define RTC_CSG_MAX_DEPTH 32  // nested CSG groups a sub-program may hold (one int of the CSG kernels' per-lane frame per level; round 2: 8)
 struct DCsgHit { double t; int32_t prim, k; };
 // A pixel's primary-hit record as the C ABI hands it out (include/rtc.h rtc_hit): packed on the device from the kernels' SoA rows.
 struct DHit { double t; int32_t prim, k; };

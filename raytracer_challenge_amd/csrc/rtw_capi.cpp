@@ -74,7 +74,7 @@ rtw_pattern* rtw_pattern_jitter(int jk, int nk, double scale, uint64_t octaves, 
   if (!child) { fail("jitter: child is NULL"); return nullptr; }
   auto p = std::make_shared<Pat>();
   p->tag = RTC_PAT_JITTER; p->kind = jk; p->noise_kind = nk; p->scale = scale; p->octaves = (uint32_t)octaves; p->left = child->p;
-  if (p->depth() > RTC_MAX_PATTERN_DEPTH) { fail("pattern deeper than RTC_MAX_PATTERN_DEPTH"); return nullptr; }
+  if (p->frame_depth() > RTC_MAX_PATTERN_DEPTH) { fail("pattern keeps more than RTC_MAX_PATTERN_DEPTH colour frames on one path (blends / gradients / colour jitters nested deeper than 8)"); return nullptr; }
   return new rtw_pattern{p};
 }
 rtw_pattern* rtw_pattern_mixture(int mk, const double t[16], const rtw_pattern* l, const rtw_pattern* r) {
@@ -82,7 +82,7 @@ rtw_pattern* rtw_pattern_mixture(int mk, const double t[16], const rtw_pattern* 
   auto p = std::make_shared<Pat>();
   p->tag = RTC_PAT_MIXTURE; p->kind = mk; p->left = l->p; p->right = r->p;
   if (!M4::from(t).invert(&p->transform_inv)) { fail("mixture: singular transform (src/linalg/matrix.rs:181)"); return nullptr; }
-  if (p->depth() > RTC_MAX_PATTERN_DEPTH) { fail("pattern deeper than RTC_MAX_PATTERN_DEPTH"); return nullptr; }
+  if (p->frame_depth() > RTC_MAX_PATTERN_DEPTH) { fail("pattern keeps more than RTC_MAX_PATTERN_DEPTH colour frames on one path (blends / gradients / colour jitters nested deeper than 8)"); return nullptr; }
   return new rtw_pattern{p};
 }
 void rtw_pattern_release(rtw_pattern* p) { delete p; }

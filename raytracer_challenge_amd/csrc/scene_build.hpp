@@ -5,11 +5,13 @@
 #include <chrono>
 #include <cstdio>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rtc.h"
@@ -18,6 +20,23 @@
 #include "host_scene.hpp"
 
 namespace rtb {
+
+// fn(begin, end) over [0, n) on a few threads (RTC_BUILD_THREADS, default: the hardware's, at most 8); small n runs inline.
+template <class F>
+inline void parallel_for(size_t n, size_t grain, F fn) {
+  unsigned t = std::thread::hardware_concurrency();
+  if (const char* e = std::getenv("RTC_BUILD_THREADS")) t = (unsigned)std::max(1, std::atoi(e));
+  t = std::min<unsigned>(std::max(1u, t), 8u);
+  if (n < 2 * grain || t < 2) { fn((size_t)0, n); return; }
+  t = (unsigned)std::min<size_t>(t, n / grain);
+  std::vector<std::thread> th;
+  const size_t per = (n + t - 1) / t;
+  for (unsigned k = 0; k < t; k++) {
+    const size_t b = std::min(n, per * k), e = std::min(n, per * (k + 1));
+    if (e > b) th.emplace_back([=] { fn(b, e); });
+  }
+  for (auto& x : th) x.join();
+}
 
 
 struct ProgramBuilder {
@@ -213,7 +232,13 @@ struct ProgramBuilder {
     const char* en = std::getenv("RTC_LIGHT_GRID_N");
     // cells per face edge: 256 (config 2: 12 % fewer candidates than 128, -4 % frame time; 64: +10 %) while the cell arrays of all
     // lights stay small beside the caches (1.5 MB per light at 256)
-    const int n = en ? std::min(512, std::max(2, std::atoi(en))) : (D.n_lights <= 4 ? 256 : (D.n_lights <= 16 ? 128 : 64));
+    // ... and while the build stays cheap: a scene of 10^4-10^5 bounded primitives gets coarser grids
+    int n = en ? std::min(512, std::max(2, std::atoi(en))) : (D.n_lights <= 4 ? 256 : (D.n_lights <= 16 ? 128 : 64));
+    if (!en && boxes.size() > 8192) n = std::min(n, boxes.size() > 65536 ? 64 : 128);
+    // Work budget: every box is counted into (and later written to) every cell its projection covers, so a light inside a cloud of
+    // large boxes costs boxes x cells; beyond 64 entries per cell on average the lists would be thrown away as RTC_LIGHT_CELL_WALK
+    // anyway: no grids then (shadow rays walk the BVH, as they did before round 2), whatever the scene.
+    const unsigned long long area_budget = 64ull * 6ull * (unsigned long long)n * (unsigned long long)n;
     // the first candidate is walked at once, the others wait on the traversal stack, whose depth the BVH decided: a cell with more
     // candidates than that holds the one reference RTC_LIGHT_CELL_WALK instead — its rays walk the BVH like any other ray
     const int max_list = std::max(8, max_stack + 1);
@@ -228,6 +253,7 @@ struct ProgramBuilder {
         return i < 0 ? 0 : (i >= n ? n - 1 : i);
       };
       bool ok = std::isfinite(o[0]) && std::isfinite(o[1]) && std::isfinite(o[2]);
+      unsigned long long area = 0;
       for (size_t k = 0; k < boxes.size() && ok; k++) {
         double a[3], b[3];  // w = l - x over the box
         for (int c = 0; c < 3; c++) { a[c] = o[c] - boxes[k].hi[c]; b[c] = o[c] - boxes[k].lo[c]; if (!(a[c] <= b[c])) ok = false; }
@@ -256,17 +282,27 @@ struct ProgramBuilder {
           }
           if (none) continue;
           Rect r{face, cell(lo2[0]), cell(hi2[0]), cell(lo2[1]), cell(hi2[1]), ref, dmin};
+          area += (unsigned long long)(r.u1 - r.u0 + 1) * (unsigned long long)(r.v1 - r.v0 + 1);
+          if (area > area_budget) { ok = false; break; }
           rects.push_back(r);
           for (int v = r.v0; v <= r.v1; v++)
             for (int u = r.u0; u <= r.u1; u++) count[((size_t)face * n + v) * n + u]++;
         }
       }
-      if (!ok) { qgrids.resize(g0); qcell.resize(c0); items.resize(i0); return 0; }
+      if (!ok) {
+        if (std::getenv("RTC_TIMING") && area > area_budget) std::fprintf(stderr, "[rtc-timing]   light grids dropped: light %u's boxes cover more than 64 entries per cell on average\n", l);
+        qgrids.resize(g0); qcell.resize(c0); items.resize(i0);
+        return 0;
+      }
       uint32_t longest = 0, walks = 0;
       unsigned long long total = 0;
       for (uint32_t& c : count) {
         longest = std::max(longest, c);
         if ((int)c > max_list) { c = 0x80000001u; walks++; } else total += c;
+      }
+      if ((unsigned long long)walks * 2ull > (unsigned long long)count.size()) {  // most cells would send their rays through the BVH anyway
+        qgrids.resize(g0); qcell.resize(c0); items.resize(i0);
+        return 0;
       }
       if (std::getenv("RTC_TIMING"))
         std::fprintf(stderr, "[rtc-timing]   light grid %u: n %d, %llu items, longest list %u, %u cells left to the BVH walk (more than %d candidates)\n", l, n, total, longest, walks, max_list);
@@ -455,11 +491,17 @@ struct ProgramBuilder {
       uint32_t base = (uint32_t)mtri_prim.size();
       int32_t fi = 0;
       int32_t root = build_tree(items, order, base, true, &fi);
-      for (uint32_t k : order) {
-        int32_t pi = ids[k];
-        const double* gq = D.tri_p1e1e2 + 9 * (size_t)D.prims[pi].data;
-        mtri.insert(mtri.end(), gq, gq + 9);
-        mtri_prim.push_back(pi);
+      {  // the mesh's triangles in leaf order (a gather of 72 B records: threads for the large meshes)
+        const size_t at = mtri_prim.size(), cnt = order.size();
+        mtri.resize((at + cnt) * 9);
+        mtri_prim.resize(at + cnt);
+        parallel_for(cnt, 65536, [&](size_t b, size_t e) {
+          for (size_t j = b; j < e; j++) {
+            const int32_t pi = ids[order[j]];
+            std::memcpy(&mtri[(at + j) * 9], D.tri_p1e1e2 + 9 * (size_t)D.prims[pi].data, 9 * sizeof(double));
+            mtri_prim[at + j] = pi;
+          }
+        });
       }
       ops.push_back({OP_MESH, root, kv.first.first, fi, kv.first.second, {0, 0, 0}});
     }
@@ -545,25 +587,36 @@ inline int validate(const rtc_scene_desc& D, std::string* err) {
   if (seen != D.n_prims) return bad("node array does not cover every primitive exactly once");
   for (uint32_t i = 0; i < D.n_materials; i++)
     if (D.materials[i].pattern < 0 || (uint32_t)D.materials[i].pattern >= D.n_pattern_nodes) return bad("material pattern index out of range");
-  // pattern nodes: children precede parents is not required; check indices + depth
-  std::vector<int> depth(D.n_pattern_nodes, 0);
-  for (uint32_t pass = 0; pass <= RTC_MAX_PATTERN_DEPTH + 1; pass++) {
+  // pattern nodes: children need not precede parents; check indices, that the graph is a forest without cycles (tree depth can be
+  // anything: the reference's Box tree is unbounded, src/material.rs:60-65) and the number of colour frames the device's walk
+  // keeps on one path (rtc_device.hpp pattern_color: Blend / RingGradient / Gradient mixtures and colour jitters): <= RTC_MAX_PATTERN_DEPTH
+  std::vector<int> depth(D.n_pattern_nodes, 0), frames(D.n_pattern_nodes, 0);
+  for (uint32_t pass = 0; pass <= D.n_pattern_nodes + 1; pass++) {
     bool changed = false;
     for (uint32_t i = 0; i < D.n_pattern_nodes; i++) {
       const rtc_pattern_node& p = D.pattern_nodes[i];
       if (p.tag < RTC_PAT_DEBUG || p.tag > RTC_PAT_MIXTURE) return bad("pattern tag out of range");
-      int d = 1;
+      int d = 1, f = 0;
       if (p.tag >= RTC_PAT_JITTER) {
         if (p.left < 0 || (uint32_t)p.left >= D.n_pattern_nodes) return bad("pattern child out of range");
         d = std::max(d, 1 + depth[p.left]);
+        f = std::max(f, frames[p.left]);
       }
       if (p.tag == RTC_PAT_MIXTURE) {
         if (p.right < 0 || (uint32_t)p.right >= D.n_pattern_nodes) return bad("pattern child out of range");
         if (p.kind < RTC_MIX_BLEND || p.kind > RTC_MIX_STRIPES) return bad("mixture kind out of range");
         d = std::max(d, 1 + depth[p.right]);
+        f = std::max(f, frames[p.right]);
       }
-      if (d != depth[i]) { depth[i] = d; changed = true; }
-      if (d > RTC_MAX_PATTERN_DEPTH) return bad("pattern tree deeper than RTC_MAX_PATTERN_DEPTH (or cyclic)");
+      const bool keeps = (p.tag == RTC_PAT_JITTER && p.kind == RTC_JITTER_COLOR) ||
+                         (p.tag == RTC_PAT_MIXTURE && (p.kind == RTC_MIX_BLEND || p.kind == RTC_MIX_RING_GRADIENT || p.kind == RTC_MIX_GRADIENT));
+      f += keeps ? 1 : 0;
+      if (d != depth[i] || f != frames[i]) { depth[i] = d; frames[i] = f; changed = true; }
+      if ((uint32_t)d > D.n_pattern_nodes) return bad("pattern nodes form a cycle");
+      if (f > RTC_MAX_PATTERN_DEPTH) {
+        *err = "a pattern keeps more than RTC_MAX_PATTERN_DEPTH colour frames on one path (blends / gradients / colour jitters nested deeper than 8)";
+        return RTC_ERR_UNSUPPORTED;
+      }
     }
     if (!changed) break;
   }
@@ -702,11 +755,16 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
   if (!pb.emit(0, D.n_nodes) || pb.status != RTC_OK) { *err = pb.error; return pb.status != RTC_OK ? pb.status : RTC_ERR_INVALID; }
   lap("program + BVH build");
   H->prims.resize(D.n_prims);
-  H->all_cast_shadow = 1;
-  for (uint32_t i = 0; i < D.n_prims; i++) {
-    H->prims[i] = {D.prims[i].geometry, D.prims[i].flags, D.prims[i].material, D.prims[i].xform, D.prims[i].data, pb.prim_gcond.empty() ? -1 : pb.prim_gcond[i], {0, 0}};
-    if (!(D.prims[i].flags & RTC_FLAG_CASTS_SHADOW)) H->all_cast_shadow = 0;
-  }
+  std::atomic<int> all_cast{1};
+  parallel_for(D.n_prims, 65536, [&](size_t b, size_t e) {
+    int cast = 1;
+    for (size_t i = b; i < e; i++) {
+      H->prims[i] = {D.prims[i].geometry, D.prims[i].flags, D.prims[i].material, D.prims[i].xform, D.prims[i].data, pb.prim_gcond.empty() ? -1 : pb.prim_gcond[i], {0, 0}};
+      if (!(D.prims[i].flags & RTC_FLAG_CASTS_SHADOW)) cast = 0;
+    }
+    if (!cast) all_cast.store(0);
+  });
+  H->all_cast_shadow = all_cast.load();
   H->xf_inv.resize((size_t)D.n_xforms * 12);
   H->xf_matinv.resize((size_t)D.n_xforms * 16);
   for (uint32_t i = 0; i < D.n_xforms; i++) {
@@ -715,15 +773,17 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
   }
   H->limits.assign(D.limits, D.limits + (size_t)D.n_limits * 2);
   H->pisect.resize(D.n_prims);
-  for (uint32_t i = 0; i < D.n_prims; i++) {
-    const DPrim& P = H->prims[i];
-    DPrimI& q = H->pisect[i];
-    q.geom = P.geom; q.flags = P.flags; q.data = P.data; q.gcond = P.gcond;
-    const bool lim = P.geom == RTC_CYLINDER || P.geom == RTC_CONE;
-    q.mn = lim ? D.limits[2 * (size_t)P.data] : 0.0;
-    q.mx = lim ? D.limits[2 * (size_t)P.data + 1] : 0.0;
-    std::memcpy(q.m, &H->xf_inv[(size_t)P.xform * 12], 12 * sizeof(double));
-  }
+  parallel_for(D.n_prims, 65536, [&](size_t b, size_t e) {
+    for (size_t i = b; i < e; i++) {
+      const DPrim& P = H->prims[i];
+      DPrimI& q = H->pisect[i];
+      q.geom = P.geom; q.flags = P.flags; q.data = P.data; q.gcond = P.gcond;
+      const bool lim = P.geom == RTC_CYLINDER || P.geom == RTC_CONE;
+      q.mn = lim ? D.limits[2 * (size_t)P.data] : 0.0;
+      q.mx = lim ? D.limits[2 * (size_t)P.data + 1] : 0.0;
+      std::memcpy(q.m, &H->xf_inv[(size_t)P.xform * 12], 12 * sizeof(double));
+    }
+  });
   H->tri_geo.assign(D.tri_p1e1e2, D.tri_p1e1e2 + (size_t)D.n_tris * 9);
   H->tri_nrm.assign(D.tri_normals, D.tri_normals + (size_t)D.n_tris * 9);
   H->mat.assign((size_t)D.n_materials * 8, 0.0);

@@ -163,6 +163,36 @@ def csg_scene():
         [floor, carved, lens, union_glass, nested, in_group, agg_child])
 
 
+def nested_pattern(kind, depth):
+    """A pattern tree `depth` mixtures deep: checkers (no colour frame on the device's walk) or blends (one frame each)."""
+    W, K = Pattern.plain(Color.white()), Pattern.plain(Color.new(0.1, 0.2, 0.6))
+    p = Pattern.stripes(Matrix.scaling(0.3, 0.3, 0.3), W, K)
+    for i in range(depth):
+        t = Matrix.rotation_y(0.3 * i) * Matrix.scaling(0.9, 0.9, 0.9)
+        p = Pattern.checkers(t, p, K) if kind == "checkers" else Pattern.blend(t, p, K)
+    return p
+
+
+def pattern_world(pattern):
+    els = [Element.plane(ShapeArgs(material=Material(pattern=pattern))),
+           Element.sphere(ShapeArgs(transform=Matrix.translation(0, 1, 0), material=Material(pattern=pattern, reflective=0.2)))]
+    cam = Camera.new(48, 32, 1.0, Camera.transform(Vector.point(0, 2.0, -5), Vector.point(0, 0.8, 0), Vector.vector(0, 1, 0)))
+    return cam, World([PointLight(Color.white(), Vector.point(-5, 8, -6))], els)
+
+
+def csg_nested(levels):
+    """Difference / Union groups nested `levels` deep around one sphere (the reference's Group::intersect recursion has no limit)."""
+    m = lambda r, g, b: Material(pattern=Pattern.plain(Color.new(r, g, b)))
+    node = Element.sphere(ShapeArgs(transform=Matrix.scaling(1.2, 1.2, 1.2), material=m(0.9, 0.3, 0.2)))
+    for i in range(levels):
+        other = Element.cube(ShapeArgs(transform=Matrix.translation(0.35 * ((i % 3) - 1), 0.3 * ((i % 2) * 2 - 1), 0.2 * (i % 4) - 0.3) * Matrix.scaling(0.5, 0.5, 0.5),
+                                       material=m(0.2 + 0.05 * i, 0.8 - 0.04 * i, 0.5)))
+        node = Element.composite(Matrix.rotation_y(0.2), None, GroupKind.Difference if i % 2 == 0 else GroupKind.Union, [node, other])
+    floor = Element.plane(ShapeArgs(transform=Matrix.translation(0, -1.5, 0)))
+    cam = Camera.new(64, 40, 0.9, Camera.transform(Vector.point(0.5, 1.5, -5), Vector.point(0, 0, 0), Vector.vector(0, 1, 0)))
+    return cam, World([PointLight(Color.white(), Vector.point(-4, 6, -6))], [node, floor])
+
+
 def edge_rays(n=4096, seed=7):
     """Rays for color_at parity: random, axis-parallel (the |d|<EPSILON slab rule), grazing, starting inside shapes, zero-ish components."""
     rng = np.random.default_rng(seed)

@@ -231,3 +231,24 @@ def test_emulated_kernel_far_rays(emu, orc):
     for name in ("all_primitives", "cube_lattice", "synthetic_mesh_small", "synthetic_cones_grouped"):
         _, world = cases.SMALL_CASES[name]()
         assert_ray_parity(emu, orc, world, cases.far_rays(512), 5, label="far " + name)
+
+
+
+def test_pattern_trees_of_any_depth(emu, orc):
+    """The reference's pattern tree is an unbounded Box tree (src/material.rs:60-65).  The device's walk keeps a frame only at nodes
+    that need both children's colours or post-process a child's colour, so the limit is on THOSE per path (RTC_MAX_PATTERN_DEPTH = 8),
+    not on the tree's depth: 24 nested checkers render like the oracle's recursion, 8 nested blends too, 9 are refused loudly."""
+    cam, world = cases.pattern_world(cases.nested_pattern("checkers", 24))
+    assert_parity(emu, orc, world, cam, 3, label="24 nested checkers")
+    cam, world = cases.pattern_world(cases.nested_pattern("blend", 8))
+    assert_parity(emu, orc, world, cam, 3, label="8 nested blends")
+    cam, world = cases.pattern_world(cases.nested_pattern("blend", 9))
+    with pytest.raises(rt.backend.RtwError, match="colour frames"):
+        emu.render(emu.build_world(world), cam, 3)
+
+
+def test_csg_nested_twelve_deep(emu, orc):
+    """Union / Difference groups nested 12 deep (round 2 refused more than 8; the reference's recursion has no limit,
+    src/shape.rs:248-269): one sub-program, post-order filters, against the oracle."""
+    cam, world = cases.csg_nested(12)
+    assert_parity(emu, orc, world, cam, 3, label="CSG nested 12 deep")

@@ -216,6 +216,21 @@ def test_hip_csg_subtrees_beyond_the_per_lane_buffer(hip, orc, path, monkeypatch
     assert_ray_parity(hip, orc, world, cases.edge_rays(2048), 5, label="CSG beyond the buffer, edge rays")
 
 
+@pytest.mark.parametrize("path", ["1", "4"])
+def test_hip_structures_beyond_round_two_limits(hip, orc, path, monkeypatch):
+    """Reference-unbounded structures (src/material.rs:60-65 pattern Box trees, src/shape.rs:248-269 nested CSG): 24 nested checkers,
+    8 nested blends and CSG groups nested 12 deep against the oracle on both device paths; 9 nested blends are refused loudly."""
+    from raytracer_challenge_amd.backend import RtwError
+    monkeypatch.setenv("RTC_KERNEL", path)
+    for label, (cam, world) in (("24 nested checkers", cases.pattern_world(cases.nested_pattern("checkers", 24))),
+                                ("8 nested blends", cases.pattern_world(cases.nested_pattern("blend", 8))),
+                                ("CSG nested 12 deep", cases.csg_nested(12))):
+        assert_parity(hip, orc, world, cam, 3, label=label + ", path " + path)
+    cam, world = cases.pattern_world(cases.nested_pattern("blend", 9))
+    with pytest.raises(RtwError, match="colour frames"):
+        hip.render(hip.build_world(world), cam, 3)
+
+
 def test_hip_config4_teapot_high_4k_fuel8(hip, orc):
     """BASELINE configs[3] on one GPU: teapot_high.obj (6 320 smooth triangles), 3840x2160, fuel 8 — full frame on the HIP path,
     a strided sample against the oracle (which tests every triangle of the flat group, src/shape.rs:254-256)."""
@@ -232,8 +247,8 @@ def test_hip_config4_teapot_high_4k_fuel8(hip, orc):
 
 def test_hip_config5_million_triangles_noise(hip, orc, tmp_path):
     """BASELINE configs[4] on one GPU: ~10^6-triangle smooth mesh (one OBJ group) with Fractal/Simplex procedural textures,
-    3840x2160, fuel 8.  Full frame on the HIP path; oracle parity on a small pixel sample AT FUEL 8 (the oracle tests
-    10^6 triangles per ray that enters the group's box: seconds per pixel); full-size property: index-list render == full-range render."""
+    3840x2160, fuel 8.  Full frame on the HIP path; oracle parity on a 512-pixel sample AT FUEL 8 (the oracle tests
+    10^6 triangles per ray that enters the group's box: seconds per pixel and thread); full-size property: index-list render == full-range render."""
     path = str(tmp_path / "heightfield_708.obj")
     ntri = scenes.write_heightfield_obj(path, 708, 708, 12345)
     assert ntri == 999698
@@ -244,10 +259,14 @@ def test_hip_config5_million_triangles_noise(hip, orc, tmp_path):
     assert np.isfinite(rgb).all()
     on_mesh = np.flatnonzero((hits["prim"] >= 1) & (hits["prim"] <= ntri))
     assert on_mesh.size > 1000000
-    idx = np.concatenate([np.arange(1000, 3840 * 2160, 3840 * 2160 // 24), on_mesh[:: on_mesh.size // 24]]).astype(np.uint64)
+    idx = np.concatenate([np.arange(1000, 3840 * 2160, 3840 * 2160 // 256), on_mesh[:: on_mesh.size // 256]]).astype(np.uint64)
+    assert idx.size >= 512
     rgb2, hits2 = hip.render(nw, cam, 8, idx)
     assert np.array_equal(rgb2, rgb[idx.astype(np.int64)]) and np.array_equal(hits2, hits[idx.astype(np.int64)])
-    assert_parity(hip, orc, world, cam, 8, idx, label="config5 sample at fuel 8 (%d px)" % idx.size)
+    # >= 512 oracle pixels (round 2: 48), primary hits AND the hit-tree digest of every pixel: one oracle pass on the box's 16 cores
+    from parity import oracle_reference
+    ref = oracle_reference(orc, world, cam, 8, idx, threads=16)
+    assert_parity(hip, orc, world, cam, 8, idx, label="config5 sample at fuel 8 (%d px)" % idx.size, ref=ref)
 
 
 def test_hip_quantiser_and_ppm(hip, orc):
