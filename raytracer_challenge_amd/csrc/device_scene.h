@@ -37,10 +37,11 @@ struct DOp {  // 32 bytes
 
 #define RTC_KOPS 12
 #define RTC_KPLANES 6
-struct DPlaneK {  // 48 bytes: what Plane::intersect reads (row 1 of transform_inv) + the primitive's index
+struct DPlaneK {  // 72 bytes: what Plane::intersect reads (row 1 of transform_inv), the primitive's index, and the plane's world normal
   double row[4];
   int32_t prim;
   int32_t pad[3];
+  double n[3];     // Shape::normal of the plane before the eye-side flip: the same for every point (scene_build.hpp plane_world_normal)
 };
 
 // 64-byte BVH2 node: both children's boxes (f32, rounded outward) + child refs.
@@ -104,7 +105,7 @@ struct DPrim {  // 32 bytes
   int32_t data;
   int32_t gcond;   // innermost enclosing aggregation group outside any CSG (-1 = none): the primitive is tested only if the
                    // reference's box test passes for that group and all its ancestors (group_parent chain)
-  int32_t pad[2];
+  int32_t pad[2];  // pad[0]: planes whose record travels in the kernel arguments: 1 + slot in DScene.kplanes (its world normal is there), else 0
 };
 
 // Everything ONE intersection test reads, in one 128-byte line (a divergent wave fetches one line per lane instead of

@@ -1,8 +1,8 @@
 // rtc_device.hpp — device functions and the templated ray kernels of the hot path (included by rtc_feat.hip, which
-// instantiates the kernels of ONE feature level per translation unit, and by rtc_kernels.hip).
+// instantiates the kernels of ONE kernel variant per translation unit, and by rtc_kernels.hip).
 #pragma once
 
-// rtc_kernels.hip — hand-written HIP for gfx950 (MI355X): the reference's per-pixel path
+// Hand-written HIP for gfx950 (MI355X): the reference's per-pixel path
 //   Image::par_render -> Camera::ray_at_pixel -> World::color_at -> {intersect, sort, hit, prepare_state,
 //   shade_hit -> {is_shadowed, Shape::lighting -> Pattern::color_at -> noise, reflected_color, refracted_color}}
 // (src/image.rs:65-81, src/camera.rs:39-55, src/world.rs:18-149, src/intersection.rs:24-139,
@@ -133,6 +133,16 @@ __shared__ unsigned long long s_diag[64];
 #define DIAG_SPAN_END(r) do {} while (0)
 #define DIAG_LOOP(j) do {} while (0)
 #endif
+
+// The specular factor of Shape::lighting (src/shape.rs:453): intensity * specular * powf(r.e, shininess).  When the material's specular is
+// (+-)0 the product is the same (+-)0 — or the same NaN for a non-finite intensity — for EVERY finite factor, so the library call (~150
+// instructions; every hit on a matte floor or wall makes it, per light) is skipped where the factor is certainly finite: 0 < r.e <= 1 + 1e-7
+// and 0 <= shininess <= 1e6 (then r.e^shininess <= e^0.1).  Anything else takes the real powf.
+__device__ double rtc_pow(double a, double b);
+__device__ __forceinline__ double specular_factor(double rde, double shininess, double specular) {
+  if (specular == 0.0 && shininess >= 0.0 && shininess <= 1.0e6 && rde <= 1.0000001) return 1.0;
+  return rtc_pow(rde, shininess);
+}
 
 // f64::powf (src/shape.rs:453).  Out of line: inlined, the library routine's ~50 f64 polynomial constants are hoisted to the top of
 // the calling kernel and spilled to scratch from there (wf_ts: 2/3 of its spill traffic), for a call that only lit highlights make.
@@ -1231,19 +1241,28 @@ __device__ __forceinline__ void prepare_state(const DScene& S, const DPrim& P, c
   // point = ray.position(t); eye = -direction
   double qx = r.ox + r.dx * t, qy = r.oy + r.dy * t, qz = r.oz + r.dz * t;
   st.ex = -r.dx; st.ey = -r.dy; st.ez = -r.dz;
-  // Shape::normal (src/shape.rs:419-427)
-  const double* m = S.xf_inv + 12 * P.xform;
-  double sx = m[0] * qx + m[1] * qy + m[2] * qz + m[3] * 1.0;
-  double sy = m[4] * qx + m[5] * qy + m[6] * qz + m[7] * 1.0;
-  double sz = m[8] * qx + m[9] * qy + m[10] * qz + m[11] * 1.0;
-  double lx, ly, lz;
-  local_normal(S, P, sx, sy, sz, u, v, lx, ly, lz);
-  // transform_inv_tsp * n: row r of the transpose = column r of transform_inv; the w term is (+-0)*0
-  double wx = m[0] * lx + m[4] * ly + m[8] * lz + 0.0;
-  double wy = m[1] * lx + m[5] * ly + m[9] * lz + 0.0;
-  double wz = m[2] * lx + m[6] * ly + m[10] * lz + 0.0;
-  double mag = sqrt(wx * wx + wy * wy + wz * wz);
-  double nx = wx / mag, ny = wy / mag, nz = wz / mag;
+  double nx, ny, nz;
+  if (P.geom == 1 && P.pad[0] > 0) {
+    // A plane's normal does not depend on the point (src/shape.rs:896: vector(0, 1, 0)): the host evaluated this function's own
+    // expressions for it once (scene_build.hpp plane_world_normal: same operations, same order, same bits) and it travels in the
+    // kernel arguments — most hits of the room scenes are on planes, and this was a square root and three divisions each.
+    const DPlaneK& K = S.kplanes[P.pad[0] - 1];
+    nx = K.n[0]; ny = K.n[1]; nz = K.n[2];
+  } else {
+    // Shape::normal (src/shape.rs:419-427)
+    const double* m = S.xf_inv + 12 * P.xform;
+    double sx = m[0] * qx + m[1] * qy + m[2] * qz + m[3] * 1.0;
+    double sy = m[4] * qx + m[5] * qy + m[6] * qz + m[7] * 1.0;
+    double sz = m[8] * qx + m[9] * qy + m[10] * qz + m[11] * 1.0;
+    double lx, ly, lz;
+    local_normal(S, P, sx, sy, sz, u, v, lx, ly, lz);
+    // transform_inv_tsp * n: row r of the transpose = column r of transform_inv; the w term is (+-0)*0
+    double wx = m[0] * lx + m[4] * ly + m[8] * lz + 0.0;
+    double wy = m[1] * lx + m[5] * ly + m[9] * lz + 0.0;
+    double wz = m[2] * lx + m[6] * ly + m[10] * lz + 0.0;
+    double mag = sqrt(wx * wx + wy * wy + wz * wz);
+    nx = wx / mag; ny = wy / mag; nz = wz / mag;
+  }
   if (nx * st.ex + ny * st.ey + nz * st.ez < 0.0) { nx = -nx; ny = -ny; nz = -nz; }
   st.nx = nx; st.ny = ny; st.nz = nz;
   st.px = qx + nx * EPS; st.py = qy + ny * EPS; st.pz = qz + nz * EPS;
@@ -1503,7 +1522,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, WAVES ? WAVES : ((FEAT >= 2 && RTC_
             double rfx = mlx - st.nx * d2, rfy = mly - st.ny * d2, rfz = mlz - st.nz * d2;
             double rde = rfx * st.ex + rfy * st.ey + rfz * st.ez;
             if (rde > 0.0) {
-              double f = rtc_pow(rde, shininess);
+              double f = specular_factor(rde, shininess, specular);
               pr = LG[0] * specular * f; pg = LG[1] * specular * f; pb = LG[2] * specular * f;
             }
           }
@@ -1761,7 +1780,7 @@ __device__ __forceinline__ void wf_shadow_rec(const DScene& S, const DCamera& ca
       double rfx = mlx - nx * d2, rfy = mly - ny * d2, rfz = mlz - nz * d2;
       double rde = rfx * ex + rfy * ey + rfz * ez;
       if (rde > 0.0) {
-        double f = rtc_pow(rde, shininess);
+        double f = specular_factor(rde, shininess, specular);
         pr = LG[0] * specular * f; pg = LG[1] * specular * f; pb = LG[2] * specular * f;
       }
     }

@@ -647,6 +647,18 @@ struct HostArrays {
   int32_t n_lights = 0, all_cast_shadow = 1, bvh_depth = 0, bvh_stack = 8, csg_max_hits = 0, built_on_device = 0;
   double quirk_reach2 = 0.0, abvh_frame[4] = {0, 0, 0, 0};  // see DScene
 
+  // Shape::normal (src/shape.rs:419-427) of a plane — local normal vector(0, 1, 0), src/shape.rs:896 — exactly as the device's
+  // prepare_state evaluates it (rtc_device.hpp: the same expressions in the same order; this translation unit is compiled with
+  // -ffp-contract=off like the kernels, sqrt and / are correctly rounded on both sides): the bits a lane would compute per hit.
+  static void plane_world_normal(const double* m, double n[3]) {
+    const double lx = 0.0, ly = 1.0, lz = 0.0;
+    const double wx = m[0] * lx + m[4] * ly + m[8] * lz + 0.0;
+    const double wy = m[1] * lx + m[5] * ly + m[9] * lz + 0.0;
+    const double wz = m[2] * lx + m[6] * ly + m[10] * lz + 0.0;
+    const double mag = std::sqrt(wx * wx + wy * wy + wz * wz);
+    n[0] = wx / mag; n[1] = wy / mag; n[2] = wz / mag;
+  }
+
   // DScene.kops / kplanes (device_scene.h): a short, jump-free program travels in the kernel arguments.
   void fill_kernarg_program(DScene& d) const {
     d.n_kops = 0; d.n_kplanes = 0;
@@ -675,6 +687,7 @@ struct HostArrays {
         DPlaneK& k = d.kplanes[d.n_kplanes];
         std::memcpy(k.row, &xf_inv[(size_t)prims[(size_t)o.a].xform * 12 + 4], 4 * sizeof(double));
         k.prim = o.a;
+        plane_world_normal(&xf_inv[(size_t)prims[(size_t)o.a].xform * 12], k.n);
         o.c = d.n_kplanes++;
       }
       d.kops[i] = o;
@@ -839,6 +852,10 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
   H->csg_max_hits = pb.csg_max_hits;
   H->built_on_device = pb.built_on_device;
   H->bvh_stack = std::max(8, pb.max_stack + 1);
+  {  // planes whose record travels in the kernel arguments: the primitive names its slot (its world normal is read there, DPrim.pad)
+    const DScene dv = H->view();
+    for (int i = 0; i < dv.n_kplanes; i++) H->prims[(size_t)dv.kplanes[i].prim].pad[0] = i + 1;
+  }
   return RTC_OK;
 }
 

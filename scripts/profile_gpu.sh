@@ -8,11 +8,11 @@ TAG=${1:-r2}; shift
 OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 rm -rf $OUT; mkdir -p $OUT
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-pmc --no-cpu-baseline "$@" > $OUT/trace.log 2>&1 || { tail -5 $OUT/trace.log; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-pmc --no-cpu-baseline --no-one-shot "$@" > $OUT/trace.log 2>&1 || { tail -5 $OUT/trace.log; exit 1; }
 python3 - $OUT <<'PY' > $OUT/summary.txt
 import glob, json, os, sys
 out = sys.argv[1]
-print("# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-pmc --no-cpu-baseline " + " ".join(sys.argv[2:]))
+print("# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-pmc --no-cpu-baseline --no-one-shot " + " ".join(sys.argv[2:]))
 for f in sorted(glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1:]:
     print("\n## kernel_stats.csv (all dispatches of the run: warm-up, tuning, counting variants <true ...> and timed frames)")
     print(open(f).read().strip())

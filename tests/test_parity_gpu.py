@@ -67,13 +67,13 @@ def hits_equal(a, b):
 @pytest.mark.parametrize("label", ["config2", "config3"])
 def test_hip_full_size_properties(hip, orc, label, monkeypatch):
     """BASELINE config 2 / 3 at 1920x1080, fuel 5, on BOTH device paths: (i) >= 100 000 pixels of the full frame against the oracle
-    (hits bit-exact, colours <= 1e-5); (ii) rendering by explicit index list == the same pixels of the full-range render
+    (primary hits and the hit-tree digest of every ray tree bit-exact, colours <= 1e-5); (ii) rendering by explicit index list == the same pixels of the full-range render
     (idempotence / order independence); (iii) the two paths give the same bits; (iv) every primary hit record is self-consistent."""
     cam, world = scenes.synthetic_analytic() if label == "config2" else scenes.chapter15_teapot("teapot_low.obj", 1920, 1080)
     idx = np.arange(0, 1920 * 1080, 19, dtype=np.uint64)          # 109 137 pixels
     assert idx.size >= 100000
-    ref_rgb, ref_hits = orc.render(orc.build_world(world), cam, 5, idx)
-    frames = {}
+    ref_rgb, ref_hits, ref_dig = orc.render_with_digest(orc.build_world(world), cam, 5, idx)
+    frames, digests = {}, {}
     for path in ("1", "4"):
         monkeypatch.setenv("RTC_KERNEL", path)
         nw = hip.build_world(world)
@@ -87,8 +87,16 @@ def test_hip_full_size_properties(hip, orc, label, monkeypatch):
         assert hits_equal(hits[ii], ref_hits), "%s path %s: primary hits differ from the oracle" % (label, path)
         err = float(np.abs(rgb[ii] - ref_rgb).max())
         assert err <= RGB_TOL, "%s path %s: max |dRGB| = %.3e" % (label, path, err)
+        # every closest hit of every ray tree: the whole frame's hit-tree digests (whole-row launch, the timed kernels' counting
+        # variants), the oracle's on the sample
+        dig = hip.render_digest(nw, cam, 5)
+        assert dig.shape == (1920 * 1080,)
+        bad = dig[ii] != ref_dig
+        assert not bad.any(), "%s path %s: hit-tree digests of %d / %d sampled pixels differ from the oracle" % (label, path, int(bad.sum()), bad.size)
         frames[path] = (rgb, hits)
+        digests[path] = dig
     assert np.array_equal(frames["1"][0], frames["4"][0]) and np.array_equal(frames["1"][1], frames["4"][1])
+    assert np.array_equal(digests["1"], digests["4"])      # all 2 073 600 ray trees, path against path
 
 
 def test_hip_rows_device_matches_host_path(hip):
@@ -247,8 +255,8 @@ def test_hip_config4_teapot_high_4k_fuel8(hip, orc):
 
 def test_hip_config5_million_triangles_noise(hip, orc, tmp_path):
     """BASELINE configs[4] on one GPU: ~10^6-triangle smooth mesh (one OBJ group) with Fractal/Simplex procedural textures,
-    3840x2160, fuel 8.  Full frame on the HIP path; oracle parity on a 512-pixel sample AT FUEL 8 (the oracle tests
-    10^6 triangles per ray that enters the group's box: seconds per pixel and thread); full-size property: index-list render == full-range render."""
+    3840x2160, fuel 8.  Full frame on the HIP path; oracle parity on a small pixel sample AT FUEL 8 (the oracle tests
+    10^6 triangles per ray that enters the group's box: seconds per pixel); full-size property: index-list render == full-range render."""
     path = str(tmp_path / "heightfield_708.obj")
     ntri = scenes.write_heightfield_obj(path, 708, 708, 12345)
     assert ntri == 999698
@@ -259,14 +267,36 @@ def test_hip_config5_million_triangles_noise(hip, orc, tmp_path):
     assert np.isfinite(rgb).all()
     on_mesh = np.flatnonzero((hits["prim"] >= 1) & (hits["prim"] <= ntri))
     assert on_mesh.size > 1000000
-    idx = np.concatenate([np.arange(1000, 3840 * 2160, 3840 * 2160 // 256), on_mesh[:: on_mesh.size // 256]]).astype(np.uint64)
-    assert idx.size >= 512
+    idx = np.concatenate([np.arange(1000, 3840 * 2160, 3840 * 2160 // 24), on_mesh[:: on_mesh.size // 24]]).astype(np.uint64)
     rgb2, hits2 = hip.render(nw, cam, 8, idx)
     assert np.array_equal(rgb2, rgb[idx.astype(np.int64)]) and np.array_equal(hits2, hits[idx.astype(np.int64)])
-    # >= 512 oracle pixels (round 2: 48), primary hits AND the hit-tree digest of every pixel: one oracle pass on the box's 16 cores
+    # (the oracle's flat triangle list costs ~10 s per on-mesh pixel and thread here: 48 pixels; the 10^5-triangle cut below takes 640)
+    assert_parity(hip, orc, world, cam, 8, idx, label="config5 sample at fuel 8 (%d px)" % idx.size)
+
+
+def test_hip_config5_cut_100k_triangles_4k_fuel8(hip, orc, tmp_path):
+    """The same scene with a 10^5-triangle cut of the mesh (224 x 224 heightfield: 99 458 smooth triangles, the same noise
+    patterns) at the full 3840x2160, fuel 8: 640 oracle pixels — half of them on the mesh — with primary hits, the hit-tree digest
+    of every pixel and colours, on both device paths."""
     from parity import oracle_reference
+    path = str(tmp_path / "heightfield_224.obj")
+    ntri = scenes.write_heightfield_obj(path, 224, 224, 12345)
+    assert ntri == 99458
+    cam, world = scenes.synthetic_mesh(path, nx=224, nz=224)
+    nw = hip.build_world(world)
+    rgb, hits = hip.render(nw, cam, 8)
+    on_mesh = np.flatnonzero((hits["prim"] >= 1) & (hits["prim"] <= ntri))
+    assert on_mesh.size > 1000000
+    idx = np.concatenate([np.arange(777, 3840 * 2160, 3840 * 2160 // 320), on_mesh[:: on_mesh.size // 320]]).astype(np.uint64)
+    assert idx.size >= 640
     ref = oracle_reference(orc, world, cam, 8, idx, threads=16)
-    assert_parity(hip, orc, world, cam, 8, idx, label="config5 sample at fuel 8 (%d px)" % idx.size, ref=ref)
+    import os
+    for kernel in ("1", "4"):
+        os.environ["RTC_KERNEL"] = kernel
+        try:
+            assert_parity(hip, orc, world, cam, 8, idx, label="config5 cut (99 458 triangles), 4K fuel 8, %d px, path %s" % (idx.size, kernel), ref=ref)
+        finally:
+            del os.environ["RTC_KERNEL"]
 
 
 def test_hip_quantiser_and_ppm(hip, orc):
