@@ -36,34 +36,23 @@
 #else
 #define TRAVERSE_INLINE __forceinline__
 #endif
-#if defined(RTC_EMU) && !defined(RTC_EMU_SIMT)
-#define RTC_LANE_ID 0  // sequential emulation: every lane is its own wave
-#else
+// Launch-geometry hooks.  A build may pre-define any of them (the CPU emulation of this source under tests/cpu_emu does, in its
+// hip_runtime.h stand-in: one-lane or thread-per-lane "waves", static arrays for LDS); what follows is the device's.
+#ifndef RTC_LANE_ID
 #define RTC_LANE_ID ((int)(threadIdx.x & 63u))
 #endif
-// wf_shade reserves queue space once per block and iteration (same-address device atomics serialise: one per wave cost 0.4 ms
-// per level); the emulators run it with one-wave blocks
-#if defined(RTC_EMU) && !defined(RTC_EMU_SIMT)
-#define RTC_WF_SHADE_BLOCK 1
-#elif defined(RTC_EMU)
-#define RTC_WF_SHADE_BLOCK 64
-#else
+// wf_shade reserves queue space once per block and iteration (same-address device atomics serialise: one per wave cost 0.4 ms per level)
 #ifndef RTC_WF_SHADE_BLOCK
 #define RTC_WF_SHADE_BLOCK 512  // measured: 128 -> +11 % frame time (more same-address atomics), 256 and 512 equal
-#endif
 #endif
 #ifndef RTC_WF_SHADE_GRID_DIV
 #define RTC_WF_SHADE_GRID_DIV 2u
 #endif
 // per-lane BVH stacks live in LDS, sized per scene at launch (DScene.bvh_stack entries per lane)
-#ifdef RTC_EMU
-#define RTC_LDS_STACK(name) static int name[RTC_BVH_STACK * RTC_BLOCK]
-#else
+#ifndef RTC_LDS_STACK
 #define RTC_LDS_STACK(name) extern __shared__ int name[]
 #endif
-#if defined(RTC_EMU) && !defined(RTC_EMU_SIMT)
-#define RTC_WF_LANES 1u
-#else
+#ifndef RTC_WF_LANES
 #define RTC_WF_LANES 64u
 #endif
 #define DINF (__builtin_inf())
@@ -73,10 +62,12 @@
 // RTC_LAUNDER(x): the compiler may not assume it knows x's value any more.  Used on a work item's index right after a traversal:
 // without it every output address derived from the index before the traversal (hipcc computes them all up front) stays live
 // across it, and at a 128-register budget that meant ~60 dwords spilled to scratch and reloaded per ray.
-#ifdef RTC_EMU
-#define RTC_LAUNDER(x) do {} while (0)
-#else
+#ifndef RTC_LAUNDER
 #define RTC_LAUNDER(x) asm volatile("" : "+v"(x))
+#endif
+// 1 / x to ~2^-24 relative (V_RCP_F64; see approx_rcp below)
+#ifndef RTC_APPROX_RCP
+#define RTC_APPROX_RCP(x) __builtin_amdgcn_rcp(x)
 #endif
 static inline unsigned rtc_stack_bytes(const DScene& S) { return (unsigned)S.bvh_stack * RTC_BLOCK * (unsigned)sizeof(int); }
 
@@ -168,19 +159,7 @@ __device__ __forceinline__ void cube_axis(double origin, double direction, doubl
 
 // 1 / x to ~2^-24 relative (V_RCP_F64: one quarter-rate instruction instead of the ~15 of a correctly rounded division); only ever
 // used where a decision tolerates far more than that and the exact expression is evaluated otherwise.
-__device__ __forceinline__ double approx_rcp(double x) {
-#ifdef RTC_EMU
-  // the CPU emulation of the kernels gives the reciprocal the error the hardware instruction may have (+-2^-23, pseudo-random per
-  // operand), so that the CPU parity tests exercise the margins of every decision built on it
-  unsigned long long bits;
-  __builtin_memcpy(&bits, &x, 8);
-  bits = (bits ^ (bits >> 29)) * 0x9E3779B97F4A7C15ull;
-  const double e = ((double)(bits >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0) * 1.1920928955078125e-07;
-  return (1.0 / x) * (1.0 + e);
-#else
-  return __builtin_amdgcn_rcp(x);
-#endif
-}
+__device__ __forceinline__ double approx_rcp(double x) { return RTC_APPROX_RCP(x); }
 
 // src/bounding_box.rs:80-92 on the group's f64 box.  The answer is a comparison of six quotients; most rays miss or cross a group's box
 // by a wide margin, so approximate quotients (reciprocals to 2^-24, margin 2^-20 of the largest quotient) settle those rays and the

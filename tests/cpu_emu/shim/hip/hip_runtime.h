@@ -24,6 +24,32 @@ static inline int hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return
 using std::fabs; using std::floor;
 // fminf/fmaxf/fabsf come from <cmath> (C functions, NaN-ignoring like the device versions)
 #define EMU_PLACEHOLDER
+// ---- the product source's launch-geometry hooks (csrc/rtc_device.hpp), as this emulation needs them
+#ifndef RTC_BLOCK
+#define RTC_BLOCK 64
+#endif
+#ifndef RTC_BVH_STACK
+#define RTC_BVH_STACK 64
+#endif
+#define RTC_LDS_STACK(name) static int name[RTC_BVH_STACK * RTC_BLOCK]
+#define RTC_LAUNDER(x) do {} while (0)
+#ifndef RTC_EMU_SIMT
+#define RTC_LANE_ID 0           // sequential emulation: every lane is its own wave
+#define RTC_WF_SHADE_BLOCK 1
+#define RTC_WF_LANES 1u
+#else
+#define RTC_WF_SHADE_BLOCK 64   // thread-per-lane emulation: one-wave blocks
+#endif
+// The emulation gives the approximate reciprocal the error the hardware instruction may have (+-2^-23, pseudo-random per operand), so
+// that the CPU parity tests exercise the margins of every decision built on it.
+static inline double rtc_emu_noisy_rcp(double x) {
+  unsigned long long bits;
+  __builtin_memcpy(&bits, &x, 8);
+  bits = (bits ^ (bits >> 29)) * 0x9E3779B97F4A7C15ull;
+  const double e = ((double)(bits >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0) * 1.1920928955078125e-07;
+  return (1.0 / x) * (1.0 + e);
+}
+#define RTC_APPROX_RCP(x) rtc_emu_noisy_rcp(x)
 using std::fabs; using std::floor; using std::fmax; using std::fmin; using std::pow; using std::sqrt;
 
 #ifndef RTC_EMU_SIMT
