@@ -637,16 +637,21 @@ __device__ __forceinline__ bool slab32c(float lx, float ly, float lz, float hx, 
 
 // One inner-node step of the walk: the node's four child boxes against the ray; hits ordered nearest first, the nearest
 // becomes `cur`, the others are stacked; no hit pops (or ends the walk: cur = END).
-template <bool PM = false>  // PM: container pass with a hit point in F (see make_frame_point)
+// PM: container pass with a hit point in F (see make_frame_point); `analytic`: the node belongs to the analytic BVH, whose leaf references carry the
+// "sphere or cube" bit in bit 0.  (A MESH leaf's low bits are its triangle count - 1: round 2 applied the point test to every leaf with bit 0 set, so
+// a container pass skipped mesh leaves of 2 or 4 triangles unless the hit point lay in their box — and missed a triangle that the line crosses once
+// before the hit, which the reference counts as a container.  Found by the hit-tree digest in a 400-seed fuzz run, seed 1058; one copy of the test
+// for analytic walks only since.)
+template <bool PM = false>
 __device__ __forceinline__ void node_step(const float4 lox, const float4 loy, const float4 loz, const float4 hix, const float4 hiy, const float4 hiz, const int4 cc,
-                                          const Frame32& F, float lo, float hi, int& cur, int& sp, int* __restrict__ stack, int stride, bool any_hit) {
+                                          const Frame32& F, float lo, float hi, int& cur, int& sp, int* __restrict__ stack, int stride, bool any_hit, bool analytic = true) {
   const float FINF = __builtin_inff();
   float t0, t1, t2, t3;
   bool h0 = slab32c(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, F, lo, hi, t0);
   bool h1 = slab32c(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, F, lo, hi, t1);
   bool h2 = slab32c(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, F, lo, hi, t2);
   bool h3 = slab32c(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, F, lo, hi, t3);
-  if (PM) {
+  if (PM && analytic) {
     if (cc.x < 0 && ((~cc.x) & 1)) h0 = h0 && point_in_box(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, F);
     if (cc.y < 0 && ((~cc.y) & 1)) h1 = h1 && point_in_box(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, F);
     if (cc.z < 0 && ((~cc.z) & 1)) h2 = h2 && point_in_box(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, F);
@@ -687,7 +692,7 @@ __device__ __forceinline__ void node_step(const float4 lox, const float4 loy, co
 // First step of a walk whose root node travels in the kernel arguments (DScene.kaux; scalar loads): every lane starts at the
 // root, so its boxes need no vector load.
 template <bool PM = false>
-__device__ __forceinline__ void walk_root_k(const DBvhNode4& R, const Frame32& F, const Trav& T, Counters& C, int& cur, int& sp, int* __restrict__ stack, int stride) {
+__device__ __forceinline__ void walk_root_k(const DBvhNode4& R, const Frame32& F, const Trav& T, Counters& C, int& cur, int& sp, int* __restrict__ stack, int stride, bool analytic) {
   C.accel_nodes++;
   C.knodes++;
   float lo, hi;
@@ -696,7 +701,7 @@ __device__ __forceinline__ void walk_root_k(const DBvhNode4& R, const Frame32& F
   const float4 loz = {R.loz[0], R.loz[1], R.loz[2], R.loz[3]}, hix = {R.hix[0], R.hix[1], R.hix[2], R.hix[3]};
   const float4 hiy = {R.hiy[0], R.hiy[1], R.hiy[2], R.hiy[3]}, hiz = {R.hiz[0], R.hiz[1], R.hiz[2], R.hiz[3]};
   const int4 cc = {R.c[0], R.c[1], R.c[2], R.c[3]};
-  node_step<PM>(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride, T.mode == MODE_SHADOW_ANY && T.unordered);
+  node_step<PM>(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride, T.mode == MODE_SHADOW_ANY && T.unordered, analytic);
 }
 
 // The walk itself, from (cur, sp): ONE inlined copy per traversal (the op loop sets the walk up per lane and all walks of a
@@ -731,11 +736,11 @@ __device__ __forceinline__ void walk_loop(const DScene& S, const bool mesh, int 
       }
       if (RTC_PROBE & 4) {  // cost probe: the node step twice (same pushes, same result)
         const int cur0 = cur, sp0 = sp;
-        node_step<PM>(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride, any_hit);
+        node_step<PM>(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride, any_hit, !mesh);
         RTC_LAUNDER(lox.x);
         cur = cur0; sp = sp0;
       }
-      node_step<PM>(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride, any_hit);
+      node_step<PM>(lox, loy, loz, hix, hiy, hiz, cc, F, lo, hi, cur, sp, stack, stride, any_hit, !mesh);
     }
     if (cur == END) return;
     {
@@ -918,7 +923,7 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
           make_frame(A.frame, o, F);
           if (MODE == MODE_CONTAINERS) make_frame_point(A.frame, o, T.thi, F);
 #ifndef RTC_NO_KROOT
-          walk_root_k<MODE == MODE_CONTAINERS>(A.root, F, T, C, cur, sp, stack, stride);
+          walk_root_k<MODE == MODE_CONTAINERS>(A.root, F, T, C, cur, sp, stack, stride, !mesh);
 #endif
         } else {
           if (mesh) o = to_object(S.xf_inv + 12 * op.b, r);

@@ -91,8 +91,22 @@ def test_random_scenes_in_the_emulator(emu, orc, seed, monkeypatch):
         assert_parity(emu, orc, world, cam, min(fuel, 3), label=label + " path " + path, ref=ref)
 
 
+def test_container_pass_counts_triangles_of_multi_triangle_leaves(emu, orc, monkeypatch):
+    """Regression (found by the hit-tree digest in a 400-seed GPU fuzz run, seed 1058): a ray inside a glass sphere starts on a mesh
+    triangle it has just been reflected off; the line crosses that triangle once BEHIND the origin, so the reference's container walk
+    (src/intersection.rs:70-103) ends with the triangle as the last container and n1 = n2 = 1.  The container pass used to apply its
+    sphere / cube point test to mesh leaves whose triangle count happened to set the same bit, skipped the leaf, and answered n1 = 1.5:
+    total internal reflection instead of a refracted ray — a pixel off by 1.5 with every primary hit still exact."""
+    cam, world, fuel, label = random_case(1058)
+    idx = np.arange(1317 - 32, 1317 + 32, dtype=np.uint64)
+    ref = oracle_reference(orc, world, cam, fuel, idx)
+    for path in ("1", "4"):
+        monkeypatch.setenv("RTC_KERNEL", path)
+        assert_parity(emu, orc, world, cam, fuel, idx, label=label + " path " + path, ref=ref)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(1000, 1000 + int(os.environ.get("RTC_FUZZ_SEEDS", "48")))))
+@pytest.mark.parametrize("seed", list(range(1000, 1000 + int(os.environ.get("RTC_FUZZ_SEEDS", "48")))) + [1058])
 def test_hip_random_scenes(hip, orc, seed, monkeypatch):
     cam, world, fuel, label = random_case(seed)
     ref = oracle_reference(orc, world, cam, fuel)   # one oracle pass, both device paths against it
