@@ -3,6 +3,7 @@ cluster, some on the floor plane), CSG groups under transformed aggregation grou
 resolutions, both device paths against the oracle — the primary hit of every pixel and the digest of every closest hit of its ray
 tree bit-exact, colours within 1e-5.  Light grids, the container passes' point test and the group gates all decide per ray which exact tests run; a scene generator
 that nobody tuned the kernels on is the cheapest way to catch a wrong decision.  RTC_FUZZ_SEEDS=<n> runs more seeds on the GPU."""
+import dataclasses
 import os
 
 import numpy as np
@@ -10,7 +11,7 @@ import pytest
 
 from parity import assert_parity, oracle_reference
 from raytracer_challenge_amd import scenes
-from raytracer_challenge_amd.scene import Color, Element, GroupKind, Material, Matrix, Pattern, PointLight, ShapeArgs, Vector
+from raytracer_challenge_amd.scene import Camera, Color, Element, GroupKind, Material, Matrix, Noise, Pattern, PointLight, ShapeArgs, Vector
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -72,8 +73,57 @@ def random_case(seed, sizes=((64, 36), (96, 54), (128, 72)), counts=(17, 40, 96,
     fuel = int(rng.choice([0, 1, 3, 5, 7]))
     if len(world.lights) > 3:
         fuel = min(fuel, 5)   # (the oracle re-traces every subtree once per light: lights ** depth)
-    label = "fuzz seed %d (n=%d cones=%s grouped=%s csg=%d mesh=%d lights=%d fuel=%d %dx%d)" % (seed, n, cones, grouped, n_csg, n_mesh, len(world.lights), fuel, h, v)
+    extra = _second_wave(rng, world, cam, tempfile.gettempdir()) if seed >= 3000 else ""
+    if isinstance(extra, tuple):
+        cam, extra = extra
+    label = "fuzz seed %d (n=%d cones=%s grouped=%s csg=%d mesh=%d lights=%d fuel=%d %dx%d%s)" % (seed, n, cones, grouped, n_csg, n_mesh, len(world.lights), fuel, h, v, extra)
     return cam, world, fuel, label
+
+
+def _shapes(elements):
+    for e in elements:
+        if e.tag == "shape":
+            yield e
+        elif e.tag == "composite":
+            yield from _shapes(e.children)
+
+
+def _second_wave(rng, world, cam, tmpdir):
+    """Seeds >= 3000 (round 3, after seed 1058): what the first generator never varied — shadowless primitives (the closest-hit shadow
+    rule, src/world.rs:43-47), a GLASS mesh (every triangle is a container of its own in the reference), procedural patterns on some
+    primitives (colours only), and a camera inside the cloud of primitives (rays that start inside glass)."""
+    tags = []
+    shapes = list(_shapes(world.elements))
+    if rng.random() < 0.4:
+        for e in shapes:
+            if rng.random() < 0.1:
+                object.__setattr__(e, "args", dataclasses.replace(e.args, casts_shadow=False))   # (the description classes are frozen)
+        tags.append("shadowless")
+    if rng.random() < 0.35:
+        n = int(rng.choice([6, 9]))
+        path = os.path.join(tmpdir, "rtc_fuzz_heightfield_%d.obj" % n)
+        if not os.path.exists(path):
+            scenes.write_heightfield_obj(path, n, n, 4242)
+        glass = Material(pattern=Pattern.plain(Color.new(0.05, 0.1, 0.1)), diffuse=0.3, transparency=0.85, reflective=float(rng.choice([0.0, 0.5])), refractive_index=float(rng.choice([1.0, 1.3, 1.5])))
+        t = Matrix.translation(float(rng.uniform(-8, 8)), float(rng.uniform(3, 12)), float(rng.uniform(-5, 10))) * Matrix.rotation_x(float(rng.uniform(-1.5, 1.5))) * Matrix.scaling(*([float(rng.uniform(0.15, 0.4))] * 3))
+        world.elements.append(Element.obj(path, t, glass))
+        tags.append("glass-mesh")
+    if rng.random() < 0.5:
+        W, K = Pattern.plain(Color.white()), Pattern.plain(Color.new(0.1, 0.2, 0.5))
+        pats = [Pattern.stripes(Matrix.scaling(0.3, 0.3, 0.3), W, K), Pattern.checkers(Matrix.rotation_y(0.4), W, K), Pattern.gradient(Matrix.scaling(2, 1, 1), W, K),
+                Pattern.blend(Matrix.id(), Pattern.ring(Matrix.scaling(0.2, 1, 0.2), W, K), Pattern.stripes(Matrix.rotation_z(0.5), K, W)),
+                Pattern.point_jitter(Noise.Simplex(0.3), Pattern.checkers(Matrix.scaling(0.4, 0.4, 0.4), W, K)), Pattern.color_jitter(Noise.Fractal(0.2, 3), Pattern.ring_gradient(Matrix.id(), W, K))]
+        for e in shapes:
+            if rng.random() < 0.2:
+                object.__setattr__(e, "args", dataclasses.replace(e.args, material=dataclasses.replace(e.args.material, pattern=pats[int(rng.integers(0, len(pats)))])))
+        tags.append("patterns")
+    if rng.random() < 0.3:
+        frm = Vector.point(float(rng.uniform(-15, 15)), float(rng.uniform(2, 18)), float(rng.uniform(-10, 20)))
+        to = Vector.point(float(rng.uniform(-5, 5)), float(rng.uniform(0, 10)), float(rng.uniform(0, 10)))
+        cam = Camera.new(cam.hsize, cam.vsize, 1.2, Camera.transform(frm, to, Vector.vector(0, 1, 0)))
+        tags.append("camera-inside")
+        return cam, " " + "+".join(tags)
+    return (" " + "+".join(tags)) if tags else ""
 
 
 @pytest.fixture(scope="module")
@@ -105,8 +155,17 @@ def test_container_pass_counts_triangles_of_multi_triangle_leaves(emu, orc, monk
         assert_parity(emu, orc, world, cam, fuel, idx, label=label + " path " + path, ref=ref)
 
 
+def _gpu_seeds():
+    """Default: 36 seeds of the first generator, 12 of the second wave (>= 3000), and 1058 (the container-pass regression).
+    RTC_FUZZ_SEEDS=<n> [RTC_FUZZ_FIRST=<seed>] runs n consecutive seeds instead (hunting runs: 400 seeds take 2.5 minutes)."""
+    if "RTC_FUZZ_SEEDS" in os.environ:
+        first = int(os.environ.get("RTC_FUZZ_FIRST", "1000"))
+        return list(range(first, first + int(os.environ["RTC_FUZZ_SEEDS"])))
+    return list(range(1000, 1036)) + list(range(3000, 3012)) + [1058]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(1000, 1000 + int(os.environ.get("RTC_FUZZ_SEEDS", "48")))) + [1058])
+@pytest.mark.parametrize("seed", _gpu_seeds())
 def test_hip_random_scenes(hip, orc, seed, monkeypatch):
     cam, world, fuel, label = random_case(seed)
     ref = oracle_reference(orc, world, cam, fuel)   # one oracle pass, both device paths against it

@@ -64,12 +64,13 @@ def hits_equal(a, b):
     return bool(np.array_equal(a["prim"], b["prim"]) and np.array_equal(a["push_idx"], b["push_idx"]) and np.array_equal(a["t"].view(np.uint64), b["t"].view(np.uint64)))
 
 
-@pytest.mark.parametrize("label", ["config2", "config3"])
+@pytest.mark.parametrize("label", ["config2", "config3", "config2_cones"])
 def test_hip_full_size_properties(hip, orc, label, monkeypatch):
-    """BASELINE config 2 / 3 at 1920x1080, fuel 5, on BOTH device paths: (i) >= 100 000 pixels of the full frame against the oracle
+    """BASELINE config 2 / 3 (and SURVEY C2's grouped variant with cones: kernel variant 5) at 1920x1080, fuel 5, on BOTH device paths: (i) >= 100 000 pixels of the full frame against the oracle
     (primary hits and the hit-tree digest of every ray tree bit-exact, colours <= 1e-5); (ii) rendering by explicit index list == the same pixels of the full-range render
     (idempotence / order independence); (iii) the two paths give the same bits; (iv) every primary hit record is self-consistent."""
-    cam, world = scenes.synthetic_analytic() if label == "config2" else scenes.chapter15_teapot("teapot_low.obj", 1920, 1080)
+    cam, world = (scenes.synthetic_analytic() if label == "config2" else scenes.synthetic_analytic(cones=True, grouped=True) if label == "config2_cones"
+                  else scenes.chapter15_teapot("teapot_low.obj", 1920, 1080))
     idx = np.arange(0, 1920 * 1080, 19, dtype=np.uint64)          # 109 137 pixels
     assert idx.size >= 100000
     ref_rgb, ref_hits, ref_dig = orc.render_with_digest(orc.build_world(world), cam, 5, idx)
