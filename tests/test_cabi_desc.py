@@ -232,3 +232,54 @@ def test_hip_render_rgb8_is_color_clamp_of_the_f64_frame(hip):
         assert np.array_equal(rgb8, want8), name
         assert st.pixels == cam.hsize * cam.vsize
         assert lib.rtc_render_rgb8(scene if False else None, C.byref(rc), 5, rgb8.ctypes.data, None) != 0   # NULL scene is refused
+
+
+@pytest.mark.gpu
+def test_hip_render_multi_random_partitions(hip):
+    """rtc_render_multi over 1-4 replicas with random image sizes (rows not a multiple of the band, fewer bands than replicas, one-row
+    images) and band heights: always the one-device frame, bit for bit; the quantised form too."""
+    lib = bind(hip.lib)
+    vp = C.c_void_p
+    from raytracer_challenge_amd.device import RtcStatsC
+    lib.rtc_multi_create.restype = C.c_int
+    lib.rtc_multi_create.argtypes = [C.POINTER(ff.RtcSceneDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    lib.rtc_multi_destroy.restype = None
+    lib.rtc_multi_destroy.argtypes = [vp]
+    lib.rtc_render_multi.restype = C.c_int
+    lib.rtc_render_multi.argtypes = [vp, C.POINTER(ff.RtcCamera), C.c_int32, vp, C.POINTER(RtcStatsC)]
+    lib.rtc_render_multi_rgb8.restype = C.c_int
+    lib.rtc_render_multi_rgb8.argtypes = [vp, C.POINTER(ff.RtcCamera), C.c_int32, vp, C.POINTER(RtcStatsC)]
+    lib.rtc_multi_set_band_rows.restype = C.c_int
+    lib.rtc_multi_set_band_rows.argtypes = [vp, C.c_uint32]
+    rng = np.random.default_rng(77)
+    cam0, world = cases.SMALL_CASES["nested_glass"]()
+    flat = ff.flatten(world)
+    desc = flat.desc()
+    multis = {}
+    for n in (1, 2, 3, 4):
+        m = vp()
+        devs = (C.c_int * n)(*([0] * n))
+        assert lib.rtc_multi_create(C.byref(desc), devs, n, C.byref(m)) == 0, lib.rtc_last_error()
+        multis[n] = m
+    scene = vp()
+    assert lib.rtc_scene_create(C.byref(desc), 0, C.byref(scene)) == 0
+    for _ in range(40):
+        hs, vs = int(rng.integers(1, 70)), int(rng.integers(1, 45))
+        n, band = int(rng.integers(1, 5)), int(rng.choice([1, 2, 3, 8, 8, 8, 16, 64]))
+        cam = Camera.new(hs, vs, cam0.field_of_view, cam0.transform_matrix)
+        rc = ff.make_camera(cam)
+        px = hs * vs
+        want = np.empty((px, 3))
+        assert lib.rtc_render(scene, C.byref(rc), 4, None, 0, px, want.ctypes.data, None, None) == 0, lib.rtc_last_error()
+        m = multis[n]
+        assert lib.rtc_multi_set_band_rows(m, band) == 0
+        got = np.full((px, 3), np.nan)
+        assert lib.rtc_render_multi(m, C.byref(rc), 4, got.ctypes.data, None) == 0, lib.rtc_last_error()
+        assert np.array_equal(got, want), (hs, vs, n, band)
+        got8 = np.zeros(3 * px, dtype=np.uint8)
+        assert lib.rtc_render_multi_rgb8(m, C.byref(rc), 4, got8.ctypes.data, None) == 0, lib.rtc_last_error()
+        c = np.minimum(want.reshape(-1), 1.0)
+        assert np.array_equal(got8, np.floor(np.maximum(c, 0.0) * 255.0 + 0.5).astype(np.uint8)), (hs, vs, n, band)
+    lib.rtc_scene_destroy(scene)
+    for m in multis.values():
+        lib.rtc_multi_destroy(m)

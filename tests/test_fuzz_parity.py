@@ -52,7 +52,138 @@ def _random_mesh(rng, tmpdir):
     return Element.composite(Matrix.rotation_y(float(rng.uniform(0, 6.28))), None, GroupKind.Aggregation, [Element.obj(path, t, mat)])
 
 
+def _third_wave(seed, sizes):
+    """Seeds >= 5000: scenes built from scratch instead of from the BASELINE generator — aggregation groups nested up to four deep with
+    their own transforms (more than 64 groups: the gate cache covers the first 64), primitive scales over five decades and clusters
+    far from the origin (the accelerator's f32 boxes live in a BVH-local frame), 1-8 lights, all five analytic kinds and small meshes."""
+    import tempfile
+    rng = np.random.default_rng(seed)
+    h, v = (int(x) for x in sizes[int(rng.integers(0, len(sizes)))])
+    centre = rng.uniform(-1, 1, 3) * float(rng.choice([1.0, 1.0, 1e3, 1e5]))
+    spread = float(rng.choice([0.05, 1.0, 1.0, 30.0]))
+
+    def material():
+        r = rng.random()
+        col = Pattern.plain(Color.new(*rng.uniform(0.05, 1.0, 3)))
+        if r < 0.5:
+            return Material(pattern=col, specular=float(rng.choice([0.0, 0.3, 0.9])), shininess=float(rng.choice([5.0, 50.0, 200.0])))
+        if r < 0.75:
+            return Material(pattern=col, reflective=float(rng.uniform(0.1, 0.9)))
+        return Material(pattern=col, diffuse=0.3, transparency=float(rng.uniform(0.3, 0.95)), reflective=float(rng.choice([0.0, 0.5, 0.9])), refractive_index=float(rng.choice([1.0, 1.1, 1.5, 2.4])))
+
+    def prim():
+        s = spread * float(10.0 ** rng.uniform(-1.5, 0.3))
+        t = Matrix.translation(*(rng.uniform(-1, 1, 3) * spread * 6)) * Matrix.rotation_y(float(rng.uniform(0, 6.28))) * Matrix.rotation_x(float(rng.uniform(0, 6.28))) * \
+            Matrix.scaling(s * float(rng.uniform(0.5, 2.0)), s * float(rng.uniform(0.5, 2.0)), s * float(rng.uniform(0.5, 2.0)))
+        a = ShapeArgs(transform=t, material=material(), casts_shadow=bool(rng.random() > 0.05))
+        k = int(rng.integers(0, 6))
+        if k == 0:
+            return Element.sphere(a)
+        if k == 1:
+            return Element.cube(a)
+        if k == 2:
+            return Element.cylinder(a, float(rng.uniform(-1.5, -0.2)), float(rng.uniform(0.2, 1.5)), bool(rng.integers(0, 2)))
+        if k == 3:
+            return Element.cone(a, float(rng.uniform(-1.2, -0.1)), float(rng.uniform(0.0, 1.0)), bool(rng.integers(0, 2)))
+        if k == 4:
+            p = rng.uniform(-1, 1, (3, 3))
+            return Element.triangle(a, Vector.point(*p[0]), Vector.point(*p[1]), Vector.point(*p[2]))
+        n = rng.normal(size=(3, 3))
+        p = rng.uniform(-1, 1, (3, 3))
+        return Element.smooth_triangle(a, Vector.point(*p[0]), Vector.point(*p[1]), Vector.point(*p[2]), Vector.vector(*n[0]), Vector.vector(*n[1]), Vector.vector(*n[2]))
+
+    n_groups = [0]
+
+    def group(depth):
+        kids = []
+        for _ in range(int(rng.integers(1, 5))):
+            if depth < 4 and rng.random() < 0.45 and n_groups[0] < 120:
+                kids.append(group(depth + 1))
+            else:
+                kids.append(prim())
+        n_groups[0] += 1
+        t = Matrix.translation(*(rng.uniform(-1, 1, 3) * spread * 2)) * Matrix.rotation_z(float(rng.uniform(-0.6, 0.6)))
+        mat = material() if rng.random() < 0.2 else None
+        return Element.composite(t, mat, GroupKind.Aggregation, kids)
+
+    body = [group(0) if rng.random() < 0.7 else prim() for _ in range(int(rng.integers(3, 40)))]
+    world_t = Matrix.translation(*centre)
+    els = [Element.composite(world_t, None, GroupKind.Aggregation, body)]
+    if rng.random() < 0.7:
+        els.append(Element.plane(ShapeArgs(transform=Matrix.translation(float(centre[0]), float(centre[1] - spread * 8), float(centre[2])), material=Material(pattern=Pattern.plain(Color.new(0.5, 0.5, 0.5)), reflective=float(rng.choice([0.0, 0.4])), specular=0.0))))
+    if rng.random() < 0.3:
+        n = int(rng.choice([6, 9]))
+        path = os.path.join(tempfile.gettempdir(), "rtc_fuzz_heightfield_%d.obj" % n)
+        if not os.path.exists(path):
+            scenes.write_heightfield_obj(path, n, n, 4242)
+        els.append(Element.obj(path, world_t * Matrix.scaling(*([spread * 0.2] * 3)), material()))
+    n_lights = int(rng.choice([1, 1, 2, 2, 3, 8]))
+    lights = [PointLight(Color.new(*rng.uniform(0.2, 0.9, 3)), Vector.point(*(centre + rng.uniform(-1, 1, 3) * spread * float(rng.choice([3.0, 15.0, 60.0]))))) for _ in range(n_lights)]
+    from raytracer_challenge_amd.scene import World
+    world = World(lights, els)
+    frm = centre + rng.uniform(-1, 1, 3) * spread * 14 + np.array([0.0, spread * 4, 0.0])
+    cam = Camera.new(h, v, float(rng.uniform(0.5, 1.6)), Camera.transform(Vector.point(*frm), Vector.point(*centre), Vector.vector(0, 1, 0)))
+    fuel = int(rng.choice([0, 2, 4, 6])) if n_lights <= 2 else (int(rng.choice([0, 2, 3])) if n_lights == 3 else int(rng.choice([0, 1])))
+    label = "fuzz seed %d (third wave: %d groups, centre %.0e, spread %g, lights=%d fuel=%d %dx%d)" % (seed, n_groups[0], float(np.abs(centre).max()), spread, n_lights, fuel, h, v)
+    return cam, world, fuel, label
+
+
+def _fourth_wave(seed, sizes):
+    """Seeds >= 20000: CSG-heavy scenes — Union / Intersection / Difference trees of random shape up to six deep (src/shape.rs:230-269), glass and
+    mirror members, aggregation groups as CSG children and CSG groups under transformed aggregation groups, sometimes more than 32 possible
+    intersections per subtree (the device's slab path), next to a few plain primitives and a floor."""
+    from raytracer_challenge_amd.scene import World
+    rng = np.random.default_rng(seed)
+    h, v = (int(x) for x in sizes[int(rng.integers(0, len(sizes)))])
+    kinds = [GroupKind.Union, GroupKind.Intersection, GroupKind.Difference]
+
+    def material():
+        r = rng.random()
+        col = Pattern.plain(Color.new(*rng.uniform(0.1, 1.0, 3)))
+        if r < 0.55:
+            return Material(pattern=col)
+        if r < 0.75:
+            return Material(pattern=col, reflective=float(rng.uniform(0.2, 0.8)))
+        return Material(pattern=col, diffuse=0.3, transparency=float(rng.uniform(0.4, 0.95)), reflective=float(rng.choice([0.0, 0.6])), refractive_index=float(rng.choice([1.0, 1.3, 1.5])))
+
+    def prim(scale=1.0):
+        t = Matrix.translation(*(rng.uniform(-0.7, 0.7, 3) * scale)) * Matrix.rotation_y(float(rng.uniform(0, 6.28))) * Matrix.rotation_z(float(rng.uniform(0, 6.28))) * \
+            Matrix.scaling(*(rng.uniform(0.5, 1.3, 3) * scale))
+        a = ShapeArgs(transform=t, material=material(), casts_shadow=bool(rng.random() > 0.1))
+        k = int(rng.integers(0, 4))
+        return Element.sphere(a) if k == 0 else Element.cube(a) if k == 1 else Element.cylinder(a, -0.9, 0.9, bool(rng.integers(0, 2))) if k == 2 else Element.cone(a, -1.0, float(rng.choice([0.0, 0.6])), True)
+
+    def csg(depth):
+        def child():
+            r = rng.random()
+            if depth < 6 and r < 0.4:
+                return csg(depth + 1)
+            if r < 0.55:
+                return Element.composite(Matrix.rotation_x(float(rng.uniform(-0.5, 0.5))), None, GroupKind.Aggregation, [prim() for _ in range(int(rng.integers(1, 7)))])
+            return prim()
+        return Element.composite(Matrix.translation(*rng.uniform(-0.3, 0.3, 3)), material() if rng.random() < 0.15 else None, kinds[int(rng.integers(0, 3))], [child(), child()])
+
+    els = []
+    for _ in range(int(rng.integers(1, 6))):
+        where = Matrix.translation(float(rng.uniform(-6, 6)), float(rng.uniform(0.5, 5)), float(rng.uniform(-3, 8))) * Matrix.scaling(*([float(rng.uniform(0.8, 2.2))] * 3))
+        node = csg(0)
+        els.append(Element.composite(where, None, GroupKind.Aggregation, [node, prim(0.5)]) if rng.random() < 0.5 else Element.composite(where, None, kinds[int(rng.integers(0, 3))], [node, prim()]))
+    for _ in range(int(rng.integers(0, 12))):
+        a = prim()
+        els.append(Element.composite(Matrix.translation(float(rng.uniform(-8, 8)), float(rng.uniform(0.5, 6)), float(rng.uniform(-4, 10))), None, GroupKind.Aggregation, [a]))
+    els.append(Element.plane(ShapeArgs(transform=Matrix.translation(0, -1.5, 0), material=Material(pattern=Pattern.checkers(Matrix.id(), Pattern.plain(Color.white()), Pattern.plain(Color.new(0.3, 0.3, 0.3))), reflective=float(rng.choice([0.0, 0.3]))))))
+    n_lights = int(rng.choice([1, 2, 2, 3]))
+    lights = [PointLight(Color.new(*rng.uniform(0.3, 0.9, 3)), Vector.point(float(rng.uniform(-10, 10)), float(rng.uniform(2, 12)), float(rng.uniform(-12, 4)))) for _ in range(n_lights)]
+    cam = Camera.new(h, v, float(rng.uniform(0.8, 1.3)), Camera.transform(Vector.point(float(rng.uniform(-4, 4)), float(rng.uniform(1, 7)), float(rng.uniform(-14, -7))), Vector.point(0, 1.5, 2), Vector.vector(0, 1, 0)))
+    fuel = int(rng.choice([0, 2, 4, 5])) if n_lights <= 2 else int(rng.choice([0, 2, 3]))
+    return cam, World(lights, els), fuel, "fuzz seed %d (fourth wave: CSG, %d top elements, lights=%d fuel=%d %dx%d)" % (seed, len(els), n_lights, fuel, h, v)
+
+
 def random_case(seed, sizes=((64, 36), (96, 54), (128, 72)), counts=(17, 40, 96, 200, 512)):
+    if seed >= 20000:
+        return _fourth_wave(seed, sizes)
+    if seed >= 5000:
+        return _third_wave(seed, sizes)
     rng = np.random.default_rng(seed)
     n = int(rng.choice(counts))
     cones, grouped = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
@@ -156,12 +287,13 @@ def test_container_pass_counts_triangles_of_multi_triangle_leaves(emu, orc, monk
 
 
 def _gpu_seeds():
-    """Default: 36 seeds of the first generator, 12 of the second wave (>= 3000), and 1058 (the container-pass regression).
+    """Default: 30 seeds of the first generator, 10 of the second wave (>= 3000), 10 of the third (>= 5000), 10 of the fourth (>= 20000: CSG), and 1058
+    (the container-pass regression).
     RTC_FUZZ_SEEDS=<n> [RTC_FUZZ_FIRST=<seed>] runs n consecutive seeds instead (hunting runs: 400 seeds take 2.5 minutes)."""
     if "RTC_FUZZ_SEEDS" in os.environ:
         first = int(os.environ.get("RTC_FUZZ_FIRST", "1000"))
         return list(range(first, first + int(os.environ["RTC_FUZZ_SEEDS"])))
-    return list(range(1000, 1036)) + list(range(3000, 3012)) + [1058]
+    return list(range(1000, 1030)) + list(range(3000, 3010)) + list(range(5000, 5010)) + list(range(20000, 20010)) + [1058]
 
 
 @pytest.mark.gpu
