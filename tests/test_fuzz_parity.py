@@ -304,3 +304,41 @@ def test_hip_random_scenes(hip, orc, seed, monkeypatch):
     for path in ("1", "4"):
         monkeypatch.setenv("RTC_KERNEL", path)
         assert_parity(hip, orc, world, cam, fuel, label=label + " path " + path, ref=ref)
+
+
+def _ray_seeds():
+    if "RTC_FUZZ_RAY_SEEDS" in os.environ:
+        first = int(os.environ.get("RTC_FUZZ_FIRST", "1000"))
+        return list(range(first, first + int(os.environ["RTC_FUZZ_RAY_SEEDS"])))
+    return [1000, 1005, 3001, 5003, 5007, 20002]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", _ray_seeds())
+def test_hip_random_scenes_edge_rays(hip, orc, seed, monkeypatch):
+    """World::color_at on rays no camera makes, in the fuzz generators' scenes: exactly axis-parallel directions, components around the
+    EPSILON threshold of the cube / bounding-box slab rule, origins inside shapes, grazing rays — every ray's own nearest hit bit-exact,
+    colours within 1e-5, both device paths (rtc_trace_rays)."""
+    import cases
+    from parity import assert_ray_parity
+    cam, world, fuel, label = random_case(seed, sizes=((32, 18),))
+    rays = cases.edge_rays(2048, seed=seed)
+    # the generators' scenes are not all around the origin: aim the ray set at what the camera looks at
+    inv = np.array(cam.transform_matrix.m, dtype=float)
+    eye = np.linalg.inv(inv)[:3, 3]
+    fwd = -np.linalg.inv(inv)[:3, 2]
+    centre = eye + fwd * (np.linalg.norm(eye) * 0.0 + 1.0) * max(1.0, float(np.linalg.norm(fwd))) * 10.0
+    scale = 1.0
+    if seed >= 5000 and seed < 20000:
+        rng = np.random.default_rng(seed)
+        rng.integers(0, 1)                       # (same first draws as _third_wave)
+        c = rng.uniform(-1, 1, 3) * float(rng.choice([1.0, 1.0, 1e3, 1e5]))
+        centre, scale = c, float(rng.choice([0.05, 1.0, 1.0, 30.0]))
+    else:
+        centre = np.array([0.0, 3.0, 3.0])
+    rays = rays.copy()
+    rays[:, :3] = rays[:, :3] * scale + centre
+    f = min(fuel, 3)
+    for path in ("1", "4"):
+        monkeypatch.setenv("RTC_KERNEL", path)
+        assert_ray_parity(hip, orc, world, rays, f, label=label + " edge rays, path " + path)
