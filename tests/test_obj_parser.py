@@ -109,3 +109,67 @@ def test_multi_group_obj_renders_like_the_oracle(orc, tmp_path):
     world = World([PointLight(Color.white(), Vector.point(-4, 6, -6))], [floor, obj])
     cam = Camera.new(80, 60, 1.0, Camera.transform(Vector.point(0.5, 2.0, -6), Vector.point(0, 1, 0), Vector.vector(0, 1, 0)))
     assert_parity(emu(), orc, world, cam, 5, label="two-group OBJ")
+
+
+def _random_obj_text(rng):
+    """A syntactically ordinary OBJ file written in as many spellings as the grammar has (src/obj.rs:54-149): number formats, runs of blanks
+    and tabs, trailing blanks, CRLF, comments and statements the parser ignores, faces as v, v/t, v//n and v/t/n, polygons, several groups."""
+    def num(x):
+        f = int(rng.integers(0, 6))
+        return [repr(float(x)), "%.4f" % x, "%e" % x, "%+.3f" % x, "%g" % x, ("%d" % round(x)) if abs(x - round(x)) < 1e-9 else "%.17g" % x][f]
+
+    def sep():
+        return [" ", "  ", "\\t", " \\t "][int(rng.integers(0, 4))]
+
+    lines, n_v, n_n = [], 0, 0
+    junk = ["# a comment", "", "vt 0.5 0.25", "usemtl shiny", "s off", "o thing", "mtllib x.mtl", "   ", "vp 0.1 0.2"]
+    for _ in range(int(rng.integers(4, 14))):
+        v = rng.uniform(-2, 2, 3)
+        lines.append("v" + sep() + sep().join(num(c) for c in v) + ("  " if rng.random() < 0.2 else ""))
+        n_v += 1
+        if rng.random() < 0.15:
+            lines.append(junk[int(rng.integers(0, len(junk)))])
+    for _ in range(int(rng.integers(0, 6))):
+        n = rng.normal(size=3)
+        lines.append("vn" + sep() + sep().join(num(c) for c in n))
+        n_n += 1
+    for g in range(int(rng.integers(1, 4))):
+        if g or rng.random() < 0.7:
+            lines.append("g" + sep() + "Group%d" % g)
+        for _ in range(int(rng.integers(0, 5))):
+            k = int(rng.integers(3, 7))
+            idx = [int(i) + 1 for i in rng.choice(n_v, size=k, replace=k > n_v)]
+            style = int(rng.integers(0, 4)) if n_n else int(rng.integers(0, 2))
+            def ref(i):
+                if style == 0:
+                    return "%d" % i
+                if style == 1:
+                    return "%d/%d" % (i, int(rng.integers(1, 9)))
+                nn = int(rng.integers(1, n_n + 1))
+                return "%d//%d" % (i, nn) if style == 2 else "%d/%d/%d" % (i, int(rng.integers(1, 9)), nn)
+            lines.append("f" + sep() + sep().join(ref(i) for i in idx))
+            if rng.random() < 0.2:
+                lines.append(junk[int(rng.integers(0, len(junk)))])
+    eol = "\\r\\n" if rng.random() < 0.25 else "\\n"
+    return eol.join(lines) + (eol if rng.random() < 0.8 else "")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RTC_OBJ_FUZZ_SEEDS", "24"))))
+def test_obj_parser_fuzz_product_vs_oracle(product, orc, seed, tmp_path):
+    """Random ordinary OBJ files: the product's loader and the oracle's separately written one agree on what they ignore and how many
+    triangles they make, and the parsed mesh renders to the same hits (emulated kernels vs the reference algorithm over the oracle's parse)."""
+    from emu_lib import emu
+    from parity import assert_parity
+    rng = np.random.default_rng(9000 + seed)
+    path = str(tmp_path / ("fuzz_%d.obj" % seed))
+    with open(path, "w", newline="") as f:
+        f.write(_random_obj_text(rng))
+    ign, tris, _ = parse(product, path)
+    o_ign, o_tris, _ = parse(orc, path)
+    assert (ign, tris) == (o_ign, o_tris), open(path).read()
+    if tris == 0:
+        return
+    mat = Material(pattern=Pattern.plain(Color.new(0.7, 0.5, 0.3)), reflective=0.2)
+    world = World([PointLight(Color.white(), Vector.point(-4, 6, -6))], [Element.plane(ShapeArgs(transform=Matrix.translation(0, -2.5, 0))), Element.obj(path, Matrix.rotation_y(0.4), mat)])
+    cam = Camera.new(48, 32, 1.0, Camera.transform(Vector.point(0.5, 1.0, -7), Vector.point(0, 0, 0), Vector.vector(0, 1, 0)))
+    assert_parity(emu(), orc, world, cam, 3, label="fuzzed OBJ %d" % seed)
