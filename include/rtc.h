@@ -32,8 +32,10 @@ enum {
                               whose CSG intersection slab would exceed RTC_CSG_MAX_BYTES (16 GiB: a subtree with more
                               than 32 possible intersections gets that many rows per thread) */
   RTC_ERR_DEVICE = 3,      /* HIP failure / no device                                                   */
-  RTC_ERR_NAN = 4          /* a NaN intersection t was produced; the reference panics when it sorts it
-                              (src/intersection.rs:124)                                                 */
+  RTC_ERR_NAN = 4          /* a NaN intersection t reached a sort the reference's comparator would run on: a list
+                              of two or more entries of one World::intersect or CSG child list; the reference
+                              panics there (src/intersection.rs:123-125).  A single NaN entry is legal: a slice
+                              of one is never compared, the ray then has no hit                          */
 };
 
 /* Geometry (src/shape.rs:466-498). */
@@ -143,7 +145,7 @@ typedef struct rtc_stats {
   uint64_t group_tests;      /* reference group boxes tested (BoundingBox::intersects; 48 B each)         */
   uint64_t tri_tests;        /* triangles tested (72 B each)                                              */
   uint64_t analytic_tests;   /* analytic primitives tested (one 128-B intersection record each)           */
-  uint64_t nan_ts;           /* NaN intersection t's seen since the last check (-> RTC_ERR_NAN)           */
+  uint64_t nan_ts;           /* passes with a NaN t in a list of >= 2 since the last check (-> RTC_ERR_NAN) */
   double kernel_ms;          /* device time of the trace kernel(s), HIP events on the scene's stream */
   uint32_t n_launches;
   uint32_t _pad;

@@ -89,8 +89,9 @@ struct Trav {
   int best_prim, best_k, best_klast;
   int shadowed;
   int unordered;  // any-hit pass that skips the nearest-first ordering of a node's children
-  int cubes_in_leaf;  // 1: this ray's reach is short enough for the padded cube boxes (DScene.quirk_reach2): BVH leaves test cubes for
-                      // quirk rays too and the cubes' quirk scan is skipped; set by traverse()
+  int flags;  // bit 0 (TF_CUBES_IN_LEAF): this ray's reach is short enough for the padded cube boxes (DScene.quirk_reach2): BVH leaves
+              //   test cubes for quirk rays too and the cubes' quirk scan is skipped; set by traverse()
+              // bit 1 (TF_NAN): a NaN t was pushed in this pass; bits 8..: intersections pushed in this pass (nan_commit())
   int light;      // shadow passes: index of the light the ray runs towards (its light grid may stand in for the BVH walk), the ray's
                   // length in c1_t; else -1
   double c1_t, c2_t;
@@ -98,6 +99,8 @@ struct Trav {
   // per-ray cache of the reference's group box tests (groups 0..63): bit set in g_known once evaluated, in g_pass if it hit
   unsigned long long g_known, g_pass;
 };
+
+enum { TF_CUBES_IN_LEAF = 1, TF_NAN = 2, TF_PUSH_SHIFT = 8 };
 
 struct Counters {
   unsigned int accel_nodes, group_tests, tri_tests, analytic_tests, nan_ts;
@@ -242,14 +245,23 @@ __device__ __forceinline__ bool key_before(double t, int prim, int k, double ht,
   return (t < ht) || (t == ht && (prim < hprim || (prim == hprim && k < hk)));
 }
 
+// The reference sorts the list of a closest-hit or shadow pass with `partial_cmp().unwrap()` (src/intersection.rs:123-125): a NaN t
+// panics when the comparator sees it, which is when the list holds at least two entries (a slice of 0 or 1 is returned as it is).
+// A NaN t comes from a ray with a NaN in it (e.g. the zero-length normal at a cone's apex), and such a ray takes every box of the
+// accelerators, so the pushes counted here are the reference's list.  Called once after a closest / shadow pass.
+__device__ __forceinline__ void nan_commit(const Trav& T, Counters& C) {
+  if ((T.flags & TF_NAN) && (T.flags >> TF_PUSH_SHIFT) >= 2) C.nan_ts++;
+}
+
 // `ks` (optional) = the original push index of each entry, when a CSG filter has dropped some of a primitive's pushes.
 __device__ __forceinline__ void accept(Trav& T, Counters& C, int prim, int n, const double* t, const int* ks = nullptr) {
   if (n == 0) return;
+  T.flags += n << TF_PUSH_SHIFT;
   if (T.mode == MODE_CLOSEST || T.mode == MODE_SHADOW_CLOSEST) {
     for (int j = 0; j < n; j++) {
       const int k = ks ? ks[j] : j;
       double tk = t[j];
-      if (tk != tk) C.nan_ts++;
+      if (tk != tk) T.flags |= TF_NAN;
       if (tk >= 0.0) {
         if (tk < T.best_t || (tk == T.best_t && prim < T.best_prim)) {
           T.best_t = tk; T.best_prim = prim; T.best_k = k; T.best_klast = k;
@@ -262,7 +274,7 @@ __device__ __forceinline__ void accept(Trav& T, Counters& C, int prim, int n, co
   } else if (T.mode == MODE_SHADOW_ANY) {
     for (int k = 0; k < n; k++) {
       double tk = t[k];
-      if (tk != tk) C.nan_ts++;
+      if (tk != tk) T.flags |= TF_NAN;
       if (tk >= 0.0 && tk < T.thi) T.shadowed = 1;
     }
   } else {  // MODE_CONTAINERS
@@ -466,7 +478,7 @@ __device__ __forceinline__ void visit_prim(const DScene& S, int prim, const Ray&
   Ray o = to_object(m, r);
   if (policy == 1) {
     bool quirk = false;
-    if (P.geom == 2) quirk = !T.cubes_in_leaf && (fabs(o.dx) < EPS || fabs(o.dy) < EPS || fabs(o.dz) < EPS);
+    if (P.geom == 2) quirk = !(T.flags & TF_CUBES_IN_LEAF) && (fabs(o.dx) < EPS || fabs(o.dy) < EPS || fabs(o.dz) < EPS);
     else if (P.geom == 4) quirk = fabs((o.dx * o.dx - o.dy * o.dy + o.dz * o.dz) - 0.0) < EPS;
     if (quirk) return;
   }
@@ -811,13 +823,15 @@ __device__ __noinline__ int csg_eval(const DScene& S, int pc, const Ray& r, Trav
       if (P.geom >= 5) C.tri_tests++; else C.analytic_tests++;
       int m = prim_hits(S, P, o, t, u, v);
       for (int j = 0; j < m && n < cap; j++) {
-        if (t[j] != t[j]) C.nan_ts++;  // the reference sorts this list: a NaN t panics (src/intersection.rs:124)
         buf[n].t = t[j]; buf[n].prim = op.a; buf[n].k = j; n++;
       }
       p++;
     } else {  // OP_CSG_END: sort [b, n) by t (stable: insertion sort), then filter_by_group
       const DCsg G = S.csg[op.c];
       int b = frame_begin[--depth];
+      if (n - b >= 2)  // the reference sorts this list: a NaN t panics once the comparator runs (src/intersection.rs:124)
+        for (int i = b; i < n; i++)
+          if (buf[i].t != buf[i].t) { C.nan_ts++; break; }
       for (int i = b + 1; i < n; i++) {
         CsgHit h = buf[i];
         int j = i - 1;
@@ -862,11 +876,11 @@ __device__ __noinline__ int csg_eval(const DScene& S, int pc, const Ray& r, Trav
 template <int FEAT, bool KOPS, int MODE = -1, bool LDSC = false>
 __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T, Counters& C, int* __restrict__ stack, int stride, const LdsScene& L = LdsScene{}) {
   if (MODE >= 0) T.mode = MODE;
-  T.cubes_in_leaf = 0;
+  T.flags = 0;
   if (S.quirk_reach2 > 0.0) {
     const double m = fmax(fmax(fabs(r.ox - S.abvh_frame[0]), fabs(r.oy - S.abvh_frame[1])), fabs(r.oz - S.abvh_frame[2])) + S.abvh_frame[3];
     const double len2 = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
-    T.cubes_in_leaf = (len2 >= 0.0025 && m * m <= S.quirk_reach2 * len2) ? 1 : 0;  // (a NaN anywhere: 0, the scan)
+    T.flags = (len2 >= 0.0025 && m * m <= S.quirk_reach2 * len2) ? TF_CUBES_IN_LEAF : 0;  // (a NaN anywhere: 0, the scan)
   }
   const LightCell lcell = light_grid_fetch<MODE>(S, r, T);
   if (KOPS) {
@@ -899,7 +913,7 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
         } else {
           visit_prim<FEAT, LDSC>(S, op.a, r, T, C, 0, L);
         }
-      } else if ((op.op == OP_QUIRK || op.op == OP_QGRID) && op.c == 1 && T.cubes_in_leaf) {
+      } else if ((op.op == OP_QUIRK || op.op == OP_QGRID) && op.c == 1 && (T.flags & TF_CUBES_IN_LEAF)) {
         // the cubes' quirk scan: this ray's leaves have tested them
       } else if (op.op == OP_QUIRK) {
         for (int i = op.a; i < op.a + op.b; i++) visit_prim<FEAT, LDSC>(S, S.quirk_prim[i], r, T, C, 2, L);
@@ -948,7 +962,7 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
     if (op.op == OP_PRIM) {
       visit_prim<FEAT, LDSC>(S, op.a, r, T, C, 0, L);
       pc++;
-    } else if ((op.op == OP_QUIRK || op.op == OP_QGRID) && op.c == 1 && T.cubes_in_leaf) {
+    } else if ((op.op == OP_QUIRK || op.op == OP_QGRID) && op.c == 1 && (T.flags & TF_CUBES_IN_LEAF)) {
       pc++;  // the cubes' quirk scan: this ray's leaves have tested them
     } else if (op.op == OP_QUIRK) {
       for (int i = op.a; i < op.a + op.b; i++) visit_prim<FEAT, LDSC>(S, S.quirk_prim[i], r, T, C, 2, L);
@@ -1279,7 +1293,7 @@ __device__ __forceinline__ void reset_closest(Trav& T, int mode) {
   T.shadowed = 0;
   T.unordered = 0;
   T.light = -1;
-  T.cubes_in_leaf = 0;
+  T.flags = 0;
   T.c1_t = 0.0; T.c2_t = 0.0; T.c1_prim = -1; T.c2_prim = -1;
   T.g_known = 0ull; T.g_pass = 0ull;
 }
@@ -1419,6 +1433,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, WAVES ? WAVES : ((FEAT >= 2 && RTC_
       Trav T;
       reset_closest(T, MODE_CLOSEST);
       traverse<FEAT, KOPS, MODE_CLOSEST>(S, ray, T, C, stack, stride);
+      nan_commit(T, C);
       DIAG_REGION(0);
       bool did_hit = T.best_prim != 0x7fffffff;
       if (COUNT && pm.digest) {
@@ -1488,6 +1503,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, WAVES ? WAVES : ((FEAT >= 2 && RTC_
           Sh.light = l; Sh.c1_t = distance;
           DIAG_T0();
           traverse<FEAT, KOPS>(S, sray, Sh, C, stack, stride);
+          nan_commit(Sh, C);
           DIAG_REGION(3);
           bool shadowed;
           if (S.all_cast_shadow) shadowed = Sh.shadowed != 0;
@@ -1645,6 +1661,7 @@ __device__ __forceinline__ void wf_trace_ray(const DScene& S, const DCamera& cam
   {
     DIAG_SPAN_BEGIN();
     traverse<FEAT, KOPS, MODE_CLOSEST, LDSC>(S, ray, T, C, stack, stride, L);
+    nan_commit(T, C);
     DIAG_SPAN_END(0);
   }
   const bool did_hit = T.best_prim != 0x7fffffff;
@@ -1716,6 +1733,7 @@ __device__ __forceinline__ void wf_shadow_rec(const DScene& S, const DCamera& ca
     DIAG_SPAN_BEGIN();
     if (S.all_cast_shadow) traverse<FEAT, KOPS, MODE_SHADOW_ANY, LDSC>(S, sray, Sh, C, stack, stride, L);  // mode: a compile-time constant in each
     else traverse<FEAT, KOPS, MODE_SHADOW_CLOSEST, LDSC>(S, sray, Sh, C, stack, stride, L);
+    nan_commit(Sh, C);
     DIAG_SPAN_END(3);
     bool shadowed;
     if (S.all_cast_shadow) shadowed = Sh.shadowed != 0;

@@ -373,7 +373,7 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
     std::fprintf(stderr, "\n");
   }
   if (h.guard) return rtc_fail(RTC_ERR_DEVICE, "traversal guard tripped (mask " + std::to_string(h.guard) + "): an index left its array; no pixel since the last check is trustworthy");
-  if (h.nan_ts) return rtc_fail(RTC_ERR_NAN, "a NaN intersection t was produced (the reference panics in Intersection::sort, src/intersection.rs:124)");
+  if (h.nan_ts) return rtc_fail(RTC_ERR_NAN, "a NaN intersection t reached a sort of two or more intersections (the reference panics in Intersection::sort, src/intersection.rs:124)");
   return RTC_OK;
 }
 
@@ -784,7 +784,7 @@ int rtc_scene_check(rtc_scene* s) {
   int rc = read_clear_sticky(s, &h);
   if (rc != RTC_OK) return rc;
   if (h.guard) return rtc_fail(RTC_ERR_DEVICE, "traversal guard tripped (mask " + std::to_string(h.guard) + ")");
-  if (h.nan_ts) return rtc_fail(RTC_ERR_NAN, "a NaN intersection t was produced (the reference panics in Intersection::sort, src/intersection.rs:124)");
+  if (h.nan_ts) return rtc_fail(RTC_ERR_NAN, "a NaN intersection t reached a sort of two or more intersections (the reference panics in Intersection::sort, src/intersection.rs:124)");
   if (h.wf_overflow) return rtc_fail(RTC_ERR_UNSUPPORTED, "a wavefront ray queue overflowed in an unsynchronised launch: render this launch synchronously (falls back by itself)");
   return RTC_OK;
 }
@@ -979,7 +979,7 @@ int render_multi(rtc_multi* m, const rtc_camera* cam, int32_t fuel, double* rgb_
     int rc = read_clear_sticky(s, &h);   // counters of the replica's launch + error state of every launch since the last check
     if (rc != RTC_OK) return rc;
     if (h.guard) return rtc_fail(RTC_ERR_DEVICE, "traversal guard tripped (mask " + std::to_string(h.guard) + ")");
-    if (h.nan_ts) return rtc_fail(RTC_ERR_NAN, "a NaN intersection t was produced (the reference panics in Intersection::sort, src/intersection.rs:124)");
+    if (h.nan_ts) return rtc_fail(RTC_ERR_NAN, "a NaN intersection t reached a sort of two or more intersections (the reference panics in Intersection::sort, src/intersection.rs:124)");
     if (h.wf_overflow) {  // an unsynchronised wavefront launch overflowed its queues: once more, synchronously (falls back by itself)
       DPixelMap pm{};
       pm.n = rows * H; pm.mode = 2; pm.row_first = k; pm.row_step = n; pm.band = B;

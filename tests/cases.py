@@ -242,3 +242,18 @@ SMALL_CASES = {
     "synthetic_mesh_small": synthetic_mesh_small,
     "csg_scene": csg_scene,
 }
+
+
+def cone_apex_world(n_planes: int):
+    """A ray through a double cone's apex: the local normal there is (0, 0, 0), its normalisation NaN, and so are over_point and the
+    shadow rays.  A NaN ray makes no cone intersection (`disc >= 0` fails) and one NaN t per plane (`|dy| < EPSILON` fails):
+    the reference's shadow list then holds `n_planes` NaNs, and its sort panics only when that is at least two (a one-element
+    slice is never compared, src/intersection.rs:123-125) -- with one plane the pixel is the ambient term."""
+    els = [Element.cone(ShapeArgs(material=Material(pattern=Pattern.plain(Color(0.2, 0.6, 0.3)), ambient=0.25)), -math.inf, math.inf, False)]
+    for i in range(n_planes):
+        els.append(Element.plane(ShapeArgs(transform=Matrix.translation(0.0, -3.0 - i, 0.0))))
+    world = World(elements=els, lights=[PointLight(Color(1.0, 1.0, 1.0), Vector.point(-4.0, 6.0, -7.0)), PointLight(Color(0.5, 0.5, 0.5), Vector.point(3.0, 5.0, -2.0))])
+    rays = np.array([[0.0, 0.0, -5.0, 0.0, 0.0, 1.0],      # the apex: t = 5 twice, object point (0, 0, 0)
+                     [0.5, 0.25, -5.0, 0.0, 0.0, 1.0],     # an ordinary cone hit
+                     [0.0, 4.0, -5.0, 0.0, -0.2, 1.0]])    # misses the cone, hits a plane
+    return world, rays

@@ -252,3 +252,19 @@ def test_csg_nested_twelve_deep(emu, orc):
     src/shape.rs:248-269): one sub-program, post-order filters, against the oracle."""
     cam, world = cases.csg_nested(12)
     assert_parity(emu, orc, world, cam, 3, label="CSG nested 12 deep")
+
+
+def test_nan_t_is_an_error_only_where_the_reference_sort_compares_it(emu, orc):
+    """Found by the edge-ray fuzz (seed 5125): a hit at a cone's apex has a NaN normal, so NaN shadow rays; the reference panics
+    on a NaN t only when its sort compares it (a list of two or more, src/intersection.rs:123-125).  One plane: the apex pixel is
+    its ambient term on both sides.  Two planes: the oracle reports the panic and the device RTC_ERR_NAN."""
+    world, rays = cases.cone_apex_world(1)
+    assert_ray_parity(emu, orc, world, rays, 3, label="cone apex, one plane")
+    rgb, hits = emu.color_at(emu.build_world(world), rays[:1], 3)
+    assert hits["prim"][0] == 0 and hits["t"][0] == 5.0 and np.allclose(rgb[0], 0.25 * np.array([0.2, 0.6, 0.3]) * 1.5)
+    world, rays = cases.cone_apex_world(2)
+    with pytest.raises(rt.backend.RtwError, match="NaN"):
+        orc.color_at(orc.build_world(world), rays, 3)
+    with pytest.raises(rt.backend.RtwError, match="NaN"):
+        emu.color_at(emu.build_world(world), rays, 3)
+    assert_ray_parity(emu, orc, world, rays[1:], 3, label="cone apex world, ordinary rays")

@@ -317,6 +317,20 @@ def test_hip_quantiser_and_ppm(hip, orc):
     assert np.array_equal(e.quantized(), orc.quantize(edge))
 
 
+@pytest.mark.parametrize("path", ["1", "4"])
+def test_hip_nan_t_is_an_error_only_where_the_reference_sort_compares_it(hip, orc, monkeypatch, path):
+    """tests/test_kernel_logic_cpu.py's case of the same name on the device, both paths: a hit at a cone's apex (NaN normal, NaN
+    shadow rays) over one plane is the ambient term, over two planes the reference's sort panics = RTC_ERR_NAN."""
+    from raytracer_challenge_amd import RtwError
+    monkeypatch.setenv("RTC_KERNEL", path)
+    world, rays = cases.cone_apex_world(1)
+    assert_ray_parity(hip, orc, world, rays, 3, label="cone apex, one plane, path " + path)
+    world, rays = cases.cone_apex_world(2)
+    with pytest.raises(RtwError, match="NaN"):
+        hip.color_at(hip.build_world(world), rays, 3)
+    assert_ray_parity(hip, orc, world, rays[1:], 3, label="cone apex world, ordinary rays, path " + path)
+
+
 def test_hip_far_rays(hip, orc):
     for name in ("all_primitives", "cube_lattice", "synthetic_mesh_small", "synthetic_cones_grouped"):
         _, world = cases.SMALL_CASES[name]()
