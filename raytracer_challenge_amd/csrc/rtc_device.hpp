@@ -344,13 +344,16 @@ __device__ __forceinline__ int prim_hits(const DScene& S, const DPrimI& P, const
   //   sphere    a = (dx dx + dy dy) + dz dz    b = 2 ((dx ox + dy oy) + dz oz)              c = ((ox ox + oy oy) + oz oz) - 1
   //   cylinder  a =  dx dx + dz dz             b = 2 ox dx + 2 oz dz  = 2 (ox dx + oz dz)   c =  (ox ox + oz oz) - 1
   //   cone      a = (dx dx - dy dy) + dz dz    b = (2 ox dx - 2 oy dy) + 2 oz dz = 2 (...)  c =  (ox ox - oy oy) + oz oz
-  // (x + 0.0 = x, x - 0.0 = x, and scaling by 2 commutes with rounding, so the shared expressions below give the same bits.)
+  // (x + (-0.0) = x and x - 0.0 = x for every x, a square is never -0.0, and scaling by 2 commutes with rounding, so the shared
+  // expressions below give the same bits -- the sign of a zero b included: a ray that starts ON a cylinder with -0.0 direction
+  // components has b = -0.0 and t = +0.0 in the reference; `+ 0.0` here made that b = +0.0 and t = -0.0 until the special-point
+  // rays of tests/cases.py found it.)
   DIAG_LOOP(13);
   const bool sph = P.geom == 0, cone = P.geom == 4;
   const double mn = P.mn, mx = P.mx;
   const double ydd = o.dy * o.dy, ydo = o.dy * o.oy, yoo = o.oy * o.oy;
   const double a = (o.dx * o.dx + (sph ? ydd : (cone ? -ydd : 0.0))) + o.dz * o.dz;
-  const double b = 2.0 * ((o.dx * o.ox + (sph ? ydo : (cone ? -ydo : 0.0))) + o.dz * o.oz);
+  const double b = 2.0 * ((o.dx * o.ox + (sph ? ydo : (cone ? -ydo : -0.0))) + o.dz * o.oz);  // -0.0: x + (-0.0) = x for x = -0.0 too
   const double c = ((o.ox * o.ox + (sph ? yoo : (cone ? -yoo : 0.0))) + o.oz * o.oz) - (cone ? 0.0 : 1.0);
   const bool a0 = fabs(a - 0.0) < EPS;
   if (cone && a0 && !(fabs(b - 0.0) < EPS)) t[n++] = -c / (2.0 * b);  // single-root branch :812-818
@@ -1286,6 +1289,18 @@ __device__ __forceinline__ double schlick(const State& st, double n1, double n2)
   return r0 + (1.0 - r0) * x5;
 }
 
+// The reference blends the reflected and the refracted colour of a reflective AND transparent surface with state.reflectance for
+// every light, whatever the fuel and whatever the two colours are (src/world.rs:70-78): a NaN reflectance -- a NaN normal, e.g. the
+// zero local normal at a cone's apex -- makes the pixel NaN even where both are black (0 * NaN).  Returns the reflectance; a NaN
+// one also poisons the surface colour, which every light's term carries.  With fuel left n1 / n2 are known and this is schlick();
+// at fuel 0 (no container pass) only the NaN-ness matters and that is eye . normal's: r0 is finite for the refractive indices
+// validate() admits (scene_build.hpp).
+__device__ __forceinline__ double blend_reflectance(const State& st, double n1, double n2, int fuel, double& cr, double& cg, double& cb) {
+  const double R = fuel > 0 ? schlick(st, n1, n2) : st.ex * st.nx + st.ey * st.ny + st.ez * st.nz;
+  if (R != R) { cr = R; cg = R; cb = R; }
+  return R;
+}
+
 __device__ __forceinline__ void reset_closest(Trav& T, int mode) {
   T.mode = mode;
   T.tlo = 0.0; T.thi = DINF;
@@ -1485,6 +1500,10 @@ __global__ void __launch_bounds__(RTC_BLOCK, WAVES ? WAVES : ((FEAT >= 2 && RTC_
           else pattern_color(S, S.mat_pattern[P.mat], x, y, z, w, cr, cg, cb);
         }
 
+        const bool blend = !LEAN && reflective > 0.0 && transparency > 0.0;  // (LEAN: DScene.no_glass_mirror)
+        double R = 0.0;
+        if (blend) R = blend_reflectance(st, n1, n2, fuel, cr, cg, cb);
+
         DIAG_REGION(2);
         // World::shade_hit (src/world.rs:50-82): per light, shadow test + Phong (src/shape.rs:429-462)
         double sr = 0.0, sg = 0.0, sb = 0.0;
@@ -1536,8 +1555,7 @@ __global__ void __launch_bounds__(RTC_BLOCK, WAVES ? WAVES : ((FEAT >= 2 && RTC_
           bool do_refl = reflective != 0.0;
           bool do_refr = transparency != 0.0;
           double wr = weight * L * reflective, wt = weight * L * transparency;
-          if (reflective > 0.0 && transparency > 0.0) {
-            double R = schlick(st, n1, n2);
+          if (blend) {
             wr *= R;
             wt *= (1.0 - R);
           }

@@ -106,6 +106,9 @@ __global__ void __launch_bounds__(RTC_WF_SHADE_BLOCK, RTC_WF_SHADE_WAVES) wf_sha
       if (!PAT || root.tag == 1) { cr = root.color[0]; cg = root.color[1]; cbl = root.color[2]; }
       else pattern_color(S, S.mat_pattern[P.mat], x, y, z, w, cr, cg, cbl);
     }
+    const bool blend = hit && reflective > 0.0 && transparency > 0.0;
+    double R = 0.0;
+    if (blend) R = blend_reflectance(st, n1, n2, fuel, cr, cg, cbl);  // (a NaN reflectance: the record's colour becomes NaN)
     // reflected_color / refracted_color (src/world.rs:84-132), once per light in the reference -> factor L
     bool do_refl = false, do_refr = false;
     double wr = 0.0, wt = 0.0, tdx = 0.0, tdy = 0.0, tdz = 0.0;
@@ -113,8 +116,7 @@ __global__ void __launch_bounds__(RTC_WF_SHADE_BLOCK, RTC_WF_SHADE_WAVES) wf_sha
       do_refl = reflective != 0.0;
       do_refr = transparency != 0.0;
       wr = weight * L * reflective; wt = weight * L * transparency;
-      if (reflective > 0.0 && transparency > 0.0) {
-        double R = schlick(st, n1, n2);
+      if (blend) {
         wr *= R;
         wt *= (1.0 - R);
       }

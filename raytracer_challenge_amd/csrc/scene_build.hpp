@@ -585,8 +585,16 @@ inline int validate(const rtc_scene_desc& D, std::string* err) {
     if (n.skip <= (int32_t)i || (uint32_t)n.skip > D.n_nodes) return bad("node skip out of range");
   }
   if (seen != D.n_prims) return bad("node array does not cover every primitive exactly once");
-  for (uint32_t i = 0; i < D.n_materials; i++)
+  for (uint32_t i = 0; i < D.n_materials; i++) {
     if (D.materials[i].pattern < 0 || (uint32_t)D.materials[i].pattern >= D.n_pattern_nodes) return bad("material pattern index out of range");
+    // the device decides at fuel 0 whether the Schlick reflectance is NaN from eye . normal alone (rtc_device.hpp schlick_or_nan): that
+    // holds for indices the formula's r0 = ((n1 - n2) / (n1 + n2))^2 is finite for
+    const double ri = D.materials[i].refractive_index;
+    if (!(ri > 1e-70 && ri < 1e70)) {
+      *err = "a material's refractive_index is not a positive finite number (1e-70 .. 1e70)";
+      return RTC_ERR_UNSUPPORTED;
+    }
+  }
   // pattern nodes: children need not precede parents; check indices, that the graph is a forest without cycles (tree depth can be
   // anything: the reference's Box tree is unbounded, src/material.rs:60-65) and the number of colour frames the device's walk
   // keeps on one path (rtc_device.hpp pattern_color: Blend / RingGradient / Gradient mixtures and colour jitters): <= RTC_MAX_PATTERN_DEPTH

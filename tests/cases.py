@@ -244,12 +244,15 @@ SMALL_CASES = {
 }
 
 
-def cone_apex_world(n_planes: int):
+def cone_apex_world(n_planes: int, glass_mirror: bool = False):
     """A ray through a double cone's apex: the local normal there is (0, 0, 0), its normalisation NaN, and so are over_point and the
     shadow rays.  A NaN ray makes no cone intersection (`disc >= 0` fails) and one NaN t per plane (`|dy| < EPSILON` fails):
     the reference's shadow list then holds `n_planes` NaNs, and its sort panics only when that is at least two (a one-element
     slice is never compared, src/intersection.rs:123-125) -- with one plane the pixel is the ambient term."""
-    els = [Element.cone(ShapeArgs(material=Material(pattern=Pattern.plain(Color(0.2, 0.6, 0.3)), ambient=0.25)), -math.inf, math.inf, False)]
+    mat = Material(pattern=Pattern.plain(Color(0.2, 0.6, 0.3)), ambient=0.25)
+    if glass_mirror:  # reflective AND transparent: the reference blends with the Schlick reflectance, NaN at the apex -> a NaN pixel
+        mat = Material(pattern=Pattern.plain(Color(0.2, 0.6, 0.3)), ambient=0.25, reflective=0.5, transparency=0.5, refractive_index=1.5)
+    els = [Element.cone(ShapeArgs(material=mat), -math.inf, math.inf, False)]
     for i in range(n_planes):
         els.append(Element.plane(ShapeArgs(transform=Matrix.translation(0.0, -3.0 - i, 0.0))))
     world = World(elements=els, lights=[PointLight(Color(1.0, 1.0, 1.0), Vector.point(-4.0, 6.0, -7.0)), PointLight(Color(0.5, 0.5, 0.5), Vector.point(3.0, 5.0, -2.0))])
@@ -257,3 +260,88 @@ def cone_apex_world(n_planes: int):
                      [0.5, 0.25, -5.0, 0.0, 0.0, 1.0],     # an ordinary cone hit
                      [0.0, 4.0, -5.0, 0.0, -0.2, 1.0]])    # misses the cone, hits a plane
     return world, rays
+
+
+def _special_points(world):
+    """World-space points where the primitives' formulas change branch or lose a derivative: a cone's apex, rims of cylinder / cone caps,
+    cube corners / edge midpoints / face centres, sphere poles, triangle vertices / edge midpoints, points of planes.  (shape, point)
+    pairs plus each primitive's object->world matrix."""
+    pts, mats = [], []
+
+    def add(M, local):
+        for p in local:
+            w = M @ np.array([p[0], p[1], p[2], 1.0])
+            if np.all(np.isfinite(w)):
+                pts.append(w[:3])
+
+    def walk(el, M):
+        if el.tag == "composite":
+            Mc = M @ np.array(el.transform.m, dtype=float)
+            for c in el.children:
+                walk(c, Mc)
+            return
+        if el.tag != "shape":
+            return
+        Ms = M @ np.array(el.args.transform.m, dtype=float)
+        mats.append(Ms)
+        g = el.geometry
+        if g == "sphere":
+            add(Ms, [(0, 1, 0), (0, -1, 0), (1, 0, 0), (-1, 0, 0), (0, 0, 1), (0, 0, -1), (0, 0, 0)])
+        elif g == "cube":
+            add(Ms, [(x, y, z) for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1)])
+        elif g in ("cylinder", "cone"):
+            lo, hi = el.params[0], el.params[1]
+            ys = [y for y in (lo, hi, 0.0) if math.isfinite(y)]
+            for y in ys:
+                r = 1.0 if g == "cylinder" else abs(y)
+                add(Ms, [(r, y, 0), (-r, y, 0), (0, y, r), (0, y, -r), (r * math.sqrt(0.5), y, r * math.sqrt(0.5)), (0, y, 0)])
+        elif g in ("triangle", "smooth_triangle"):
+            p = np.array(el.params[:9]).reshape(3, 3)
+            add(Ms, [p[0], p[1], p[2], (p[0] + p[1]) / 2, (p[1] + p[2]) / 2, (p[0] + p[2]) / 2, (p[0] + p[1] + p[2]) / 3])
+        elif g == "plane":
+            add(Ms, [(0, 0, 0), (1, 0, 0), (0, 0, 1), (-3, 0, 2)])
+
+    for el in world.elements:
+        walk(el, np.eye(4))
+    return np.array(pts).reshape(-1, 3), mats
+
+
+def special_rays(world, n=2048, seed=11):
+    """Rays for color_at parity aimed at `_special_points`: from a random origin through one; from one to another (what shadow and
+    reflection rays between primitives look like); starting exactly on one; through one along an axis of its primitive's object space
+    (exactly axis-parallel object rays where the transform is a translation / power-of-two scaling); towards the lights."""
+    rng = np.random.default_rng(seed)
+    pts, mats = _special_points(world)
+    if len(pts) == 0:
+        return edge_rays(n, seed)
+    lo, hi = pts.min(axis=0), pts.max(axis=0)
+    span = np.maximum(hi - lo, 1.0)
+    rays = np.zeros((n, 6))
+    lights = np.array([list(l.origin[:3]) for l in world.lights]) if world.lights else np.zeros((1, 3))
+    for i in range(n):
+        kind = i % 6
+        tgt = pts[rng.integers(len(pts))]
+        if kind == 0:      # random origin in the cloud's box (inflated) through the point
+            o = lo - span + rng.random(3) * 3 * span
+            d = tgt - o
+        elif kind == 1:    # point to point
+            o = pts[rng.integers(len(pts))]
+            d = tgt - o
+        elif kind == 2:    # starts exactly on the point, random direction
+            o, d = tgt, rng.normal(size=3)
+        elif kind == 3:    # through the point along an object-space axis of some primitive
+            M = mats[rng.integers(len(mats))]
+            a = M[:3, rng.integers(3)] * float(rng.choice([-1.0, 1.0]))
+            d = a
+            o = tgt - a * float(rng.choice([1.0, 2.0, 4.0, 0.5]))
+        elif kind == 4:    # from the point towards a light / from a light to the point
+            L = lights[rng.integers(len(lights))]
+            o, d = (tgt, L - tgt) if rng.random() < 0.5 else (L, tgt - L)
+        else:              # starts on the point, heads along an object-space axis (grazes faces / caps / the plane)
+            M = mats[rng.integers(len(mats))]
+            o, d = tgt, M[:3, rng.integers(3)] * float(rng.choice([-1.0, 1.0]))
+        ln = float(np.linalg.norm(d))
+        if not (ln > 1e-300 and math.isfinite(ln)):
+            d, ln = np.array([0.0, 0.0, 1.0]), 1.0
+        rays[i, :3], rays[i, 3:] = o, d / ln   # unit directions (an exactly axis-parallel one stays exactly so)
+    return rays

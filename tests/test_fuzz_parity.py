@@ -342,3 +342,18 @@ def test_hip_random_scenes_edge_rays(hip, orc, seed, monkeypatch):
     for path in ("1", "4"):
         monkeypatch.setenv("RTC_KERNEL", path)
         assert_ray_parity(hip, orc, world, rays, f, label=label + " edge rays, path " + path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", _ray_seeds())
+def test_hip_random_scenes_special_rays(hip, orc, seed, monkeypatch):
+    """The generators' scenes under rays aimed at their primitives' special points (cases.special_rays: cone apexes, cap rims, cube
+    corners / edges, poles, triangle vertices / edges, from and to the lights, along object-space axes) -- the ray set that found the
+    NaN-reflectance blend and the sign of a zero t on cylinders.  Both device paths; rays the reference panics on are refused singly."""
+    import cases
+    from parity import assert_ray_parity_with_panics
+    cam, world, fuel, label = random_case(seed, sizes=((32, 18),))
+    rays = cases.special_rays(world, 1536, seed=seed)
+    for path in ("1", "4"):
+        monkeypatch.setenv("RTC_KERNEL", path)
+        assert_ray_parity_with_panics(hip, orc, world, rays, min(fuel, 3), label=label + " special rays, path " + path)

@@ -9,7 +9,7 @@ import pytest
 
 from raytracer_challenge_amd import scenes
 import cases
-from parity import RGB_TOL, assert_parity, assert_ray_parity
+from parity import RGB_TOL, assert_parity, assert_ray_parity, assert_ray_parity_with_panics
 from test_oracle_pins import SCENES as GOLDEN_SCENES, load_samples
 
 pytestmark = pytest.mark.gpu
@@ -329,6 +329,32 @@ def test_hip_nan_t_is_an_error_only_where_the_reference_sort_compares_it(hip, or
     with pytest.raises(RtwError, match="NaN"):
         hip.color_at(hip.build_world(world), rays, 3)
     assert_ray_parity(hip, orc, world, rays[1:], 3, label="cone apex world, ordinary rays, path " + path)
+
+
+@pytest.mark.parametrize("path", ["1", "4"])
+def test_hip_nan_reflectance_makes_the_pixel_nan_as_in_the_reference(hip, orc, monkeypatch, path):
+    """A reflective AND transparent cone hit at its apex: NaN Schlick reflectance, and the reference's blend of two black colours with it
+    is NaN at every fuel (src/world.rs:70-78).  Rays and a 9x9 camera whose centre pixel is that ray, both device paths."""
+    from raytracer_challenge_amd.scene import Camera, Vector
+    monkeypatch.setenv("RTC_KERNEL", path)
+    world, rays = cases.cone_apex_world(1, glass_mirror=True)
+    for fuel in (0, 1, 3):
+        rgb, _ = hip.color_at(hip.build_world(world), rays, fuel)
+        assert np.isnan(rgb[0]).all() and np.isfinite(rgb[1:]).all()
+        assert_ray_parity(hip, orc, world, rays, fuel, label="glass-mirror cone apex, fuel %d, path %s" % (fuel, path))
+    cam = Camera.new(9, 9, 0.5, Camera.transform(Vector.point(0, 0, -5), Vector.point(0, 0, 0), Vector.vector(0, 1, 0)))
+    assert_parity(hip, orc, world, cam, 3, label="glass-mirror cone apex through a camera, path " + path)
+
+
+def test_hip_special_point_rays(hip, orc, monkeypatch):
+    """cases.special_rays (aimed at apexes, rims, corners, edges, poles, vertices; from / to lights; along object-space axes) on the small
+    scenes, both device paths; rays the reference panics on must be refused one by one (tests/parity.py)."""
+    for name in ("all_primitives", "nested_glass", "nested_groups", "cube_lattice", "synthetic_cones_grouped", "csg_scene", "synthetic_mesh_small"):
+        _, world = cases.SMALL_CASES[name]()
+        rays = cases.special_rays(world, 6144)
+        for path in ("1", "4"):
+            monkeypatch.setenv("RTC_KERNEL", path)
+            assert_ray_parity_with_panics(hip, orc, world, rays, 5, label="special rays %s path %s" % (name, path))
 
 
 def test_hip_far_rays(hip, orc):
