@@ -271,6 +271,9 @@ int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb,
         const AfterLaunch* after = nullptr) {
   if (fuel < 0) fuel = 0;  // fuel <= 0 spawns nothing (src/world.rs:90,110)
   if (fuel > RTC_MAX_FUEL) return rtc_fail(RTC_ERR_INVALID, "fuel exceeds RTC_MAX_FUEL");
+  // World::shade_hit calls reflected_color / refracted_color inside its loop over the lights (src/world.rs:58-79): a world without
+  // lights traces no secondary ray at all (and shades every hit black)
+  if (s->d.n_lights == 0) fuel = 0;
   HIP_OK(hipSetDevice(s->device));
   // only the per-launch counters are zeroed: the error fields behind them accumulate until somebody reads them
   HIP_OK(hipMemsetAsync(s->d_stats, 0, RTC_STATS_LAUNCH_BYTES, s->stream));

@@ -4,9 +4,10 @@ import numpy as np
 RGB_TOL = 1e-5  # BASELINE.json north_star: "pixels match the reference CPU render within 1e-5 per RGB channel"
 
 
-def rgb_error(rgb, ref_rgb, label=""):
+def rgb_error(rgb, ref_rgb, label="", rel=False):
     """max |dRGB| over the finite channels; channels the reference makes NaN or infinite (0 * NaN blends at a NaN normal, specular
-    overflow) must be the same NaN / the same infinity on the device."""
+    overflow) must be the same NaN / the same infinity on the device.  rel: errors relative to max(1, |reference|) -- for ray sets
+    with directions that are not unit vectors, where `reflect . eye` exceeds 1 and its power the range of a colour."""
     if not rgb.size:
         return 0.0
     odd_t, odd_r = ~np.isfinite(rgb), ~np.isfinite(ref_rgb)
@@ -14,7 +15,10 @@ def rgb_error(rgb, ref_rgb, label=""):
     assert same.all(), "%s: %d channels are NaN / infinite on one side only, first at %s: got %s want %s" % (
         label, int((~same).sum()), np.argwhere(~same)[:3].tolist(), rgb[~same][:3], ref_rgb[~same][:3])
     fin = ~odd_r
-    return float(np.abs(rgb[fin] - ref_rgb[fin]).max()) if fin.any() else 0.0
+    if not fin.any():
+        return 0.0
+    d = np.abs(rgb[fin] - ref_rgb[fin])
+    return float((d / np.maximum(1.0, np.abs(ref_rgb[fin]))).max() if rel else d.max())
 
 
 def oracle_reference(orc, world, camera, fuel=5, pixel_indices=None, threads=0):
@@ -48,13 +52,13 @@ def assert_parity(test_backend, orc, world, camera, fuel=5, pixel_indices=None, 
     return err
 
 
-def assert_ray_parity(test_backend, orc, world, rays, fuel=5, label=""):
+def assert_ray_parity(test_backend, orc, world, rays, fuel=5, label="", rel=False):
     nw_t, nw_o = test_backend.build_world(world), orc.build_world(world)
     rgb, hits = test_backend.color_at(nw_t, rays, fuel)
     ref_rgb, ref_hits = orc.color_at(nw_o, rays, fuel)
     bad = (hits["prim"] != ref_hits["prim"]) | (hits["push_idx"] != ref_hits["push_idx"]) | (hits["t"].view(np.uint64) != ref_hits["t"].view(np.uint64))
     assert not bad.any(), "%s: %d/%d hit records differ: got %s want %s" % (label, int(bad.sum()), bad.size, hits[bad][:3], ref_hits[bad][:3])
-    err = rgb_error(rgb, ref_rgb, label)
+    err = rgb_error(rgb, ref_rgb, label, rel)
     assert err <= RGB_TOL, "%s: max |dRGB| = %.3e" % (label, err)
     return err
 
@@ -69,7 +73,7 @@ def _raises(backend, nw, rays, fuel):
         return True
 
 
-def assert_ray_parity_with_panics(test_backend, orc, world, rays, fuel=5, label="", max_panics=64):
+def assert_ray_parity_with_panics(test_backend, orc, world, rays, fuel=5, label="", max_panics=64, rel=False):
     """assert_ray_parity for ray sets that may hold rays on which the reference PANICS (a NaN t reaches its sort,
     src/intersection.rs:123-125): those rays are found with the oracle (bisection), the device must refuse each of them alone with
     RTC_ERR_NAN, and the rest of the set must match hit for hit.  Returns (max |dRGB|, number of panicking rays)."""
@@ -92,4 +96,4 @@ def assert_ray_parity_with_panics(test_backend, orc, world, rays, fuel=5, label=
         assert _raises(test_backend, nw_t, rays[i:i + 1], fuel), "%s: the reference panics on ray %d %s, the device does not" % (label, i, rays[i])
     keep = np.ones(len(rays), dtype=bool)
     keep[panics] = False
-    return assert_ray_parity(test_backend, orc, world, rays[keep], fuel, label=label), len(panics)
+    return assert_ray_parity(test_backend, orc, world, rays[keep], fuel, label=label, rel=rel), len(panics)

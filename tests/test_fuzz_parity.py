@@ -4,6 +4,7 @@ resolutions, both device paths against the oracle — the primary hit of every p
 tree bit-exact, colours within 1e-5.  Light grids, the container passes' point test and the group gates all decide per ray which exact tests run; a scene generator
 that nobody tuned the kernels on is the cheapest way to catch a wrong decision.  RTC_FUZZ_SEEDS=<n> runs more seeds on the GPU."""
 import dataclasses
+import math
 import os
 
 import numpy as np
@@ -11,7 +12,7 @@ import pytest
 
 from parity import assert_parity, oracle_reference
 from raytracer_challenge_amd import scenes
-from raytracer_challenge_amd.scene import Camera, Color, Element, GroupKind, Material, Matrix, Noise, Pattern, PointLight, ShapeArgs, Vector
+from raytracer_challenge_amd.scene import Camera, Color, Element, GroupKind, Material, Matrix, Noise, Pattern, PointLight, ShapeArgs, Vector, World
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -179,7 +180,106 @@ def _fourth_wave(seed, sizes):
     return cam, World(lights, els), fuel, "fuzz seed %d (fourth wave: CSG, %d top elements, lights=%d fuel=%d %dx%d)" % (seed, len(els), n_lights, fuel, h, v)
 
 
+def _fifth_wave(seed, sizes):
+    """Seeds >= 40000: LATTICE scenes.  Every transform is translation(integers or halves) x signed axis permutation x scaling(powers of
+    two), every limit and vertex an integer or a half, lights on lattice points: products, inverses and most intersections are EXACT, so
+    the ties and thresholds random scenes never meet are met all the time -- tangent rays (discriminant exactly 0), rays through cube
+    edges and corners (t_min == t_max), along faces, through triangle vertices and edges (u = 0, u + v = 1), a cone's apex, cap rims
+    (x^2 + z^2 == r^2), y == limit, coincident faces of neighbours and of CSG operands (equal t: the sort's stability decides), lights
+    on surfaces.  To be used with lattice_rays()."""
+    rng = np.random.default_rng(seed)
+    h, v = (int(x) for x in sizes[int(rng.integers(0, len(sizes)))])
+    kinds = [GroupKind.Union, GroupKind.Intersection, GroupKind.Difference]
+
+    def lattice(n=3, lo=-4, hi=4):
+        return [float(x) for x in (rng.integers(2 * lo, 2 * hi + 1, n) / 2.0 if rng.random() < 0.3 else rng.integers(lo, hi + 1, n))]
+
+    def transform(spread=4):
+        perm = rng.permutation(3)
+        P = [[0.0] * 4 for _ in range(4)]
+        for r in range(3):
+            P[r][int(perm[r])] = float(rng.choice([-1.0, 1.0]))
+        P[3][3] = 1.0
+        sc = [float(rng.choice([0.5, 1.0, 1.0, 2.0]))] * 3 if rng.random() < 0.6 else [float(x) for x in rng.choice([0.5, 1.0, 2.0], 3)]
+        return Matrix.translation(*lattice(3, -spread, spread)) * Matrix(P) * Matrix.scaling(*sc)
+
+    def pattern():
+        r = rng.random()
+        a, b = Pattern.plain(Color.new(*rng.uniform(0.1, 1.0, 3))), Pattern.plain(Color.new(*rng.uniform(0.0, 0.9, 3)))
+        if r < 0.6:
+            return a
+        t = Matrix.scaling(*[float(rng.choice([0.5, 1.0, 2.0]))] * 3)
+        return [Pattern.checkers, Pattern.stripes, Pattern.ring, Pattern.gradient][int(rng.integers(0, 4))](t, a, b)
+
+    def material():
+        r = rng.random()
+        refl = float(rng.choice([0.0, 0.0, 0.5, 1.0]))
+        tr = float(rng.choice([0.0, 0.0, 0.5, 1.0]))
+        return Material(pattern=pattern(), ambient=float(rng.choice([0.0, 0.1, 0.5])), diffuse=float(rng.choice([0.0, 0.5, 0.9])), specular=float(rng.choice([0.0, 0.5, 0.9])),
+                        shininess=float(rng.choice([1.0, 10.0, 200.0])), reflective=refl, transparency=tr, refractive_index=float(rng.choice([1.0, 1.0, 1.5, 2.0])))
+
+    def prim(spread=4):
+        a = ShapeArgs(transform=transform(spread), material=material(), casts_shadow=bool(rng.random() > 0.15))
+        k = int(rng.integers(0, 6))
+        if k == 0:
+            return Element.sphere(a)
+        if k == 1:
+            return Element.cube(a)
+        if k in (2, 3):
+            lo_, hi_ = sorted(float(x) for x in rng.choice([-2.0, -1.0, -0.5, 0.0, 0.5, 1.0, 2.0], 2, replace=False))
+            if rng.random() < 0.15:
+                lo_ = -math.inf
+            if rng.random() < 0.15:
+                hi_ = math.inf
+            return (Element.cylinder if k == 2 else Element.cone)(a, lo_, hi_, bool(rng.integers(0, 2)))
+        if k == 4:
+            while True:
+                p = [Vector.point(*lattice(3, -2, 2)) for _ in range(3)]
+                e1, e2 = np.array(p[1][:3]) - np.array(p[0][:3]), np.array(p[2][:3]) - np.array(p[0][:3])
+                if np.linalg.norm(np.cross(e1, e2)) > 0:
+                    return Element.triangle(a, *p)
+        return Element.plane(a)
+
+    def csg(depth):
+        def child():
+            return csg(depth + 1) if depth < 2 and rng.random() < 0.3 else prim(1)
+        return Element.composite(transform(3), material() if rng.random() < 0.2 else None, kinds[int(rng.integers(0, 3))], [child(), child()])
+
+    els = []
+    for _ in range(int(rng.integers(3, 25))):
+        r = rng.random()
+        if r < 0.6:
+            els.append(prim())
+        elif r < 0.8:
+            els.append(Element.composite(transform(3), material() if rng.random() < 0.3 else None, GroupKind.Aggregation, [prim(2) for _ in range(int(rng.integers(1, 6)))]))
+        else:
+            els.append(csg(0))
+    n_lights = int(rng.choice([0, 1, 1, 2, 3]))
+    lights = [PointLight(Color.new(*rng.choice([0.0, 0.5, 1.0], 3)), Vector.point(*lattice(3, -6, 6))) for _ in range(n_lights)]
+    cam = Camera.new(h, v, 1.0, Camera.transform(Vector.point(0, 2, -12), Vector.point(0, 0, 0), Vector.vector(0, 1, 0)))
+    fuel = int(rng.choice([0, 1, 2, 3]))
+    return cam, World(lights, els), fuel, "fuzz seed %d (fifth wave: lattice, %d top elements, lights=%d fuel=%d)" % (seed, len(els), n_lights, fuel)
+
+
+def lattice_rays(n, seed):
+    """Rays for _fifth_wave scenes: origins on the half-integer lattice of [-6, 6]^3, directions small integer vectors (exact tangents,
+    edges, corners, apexes), every second one normalised."""
+    rng = np.random.default_rng(seed + 77)
+    o = rng.integers(-12, 13, (n, 3)) / 2.0
+    o[: n // 2] = np.round(o[: n // 2])
+    d = rng.integers(-2, 3, (n, 3)).astype(float)
+    axis = rng.random(n) < 0.3
+    d[axis] = np.eye(3)[rng.integers(0, 3, int(axis.sum()))] * rng.choice([-1.0, 1.0], (int(axis.sum()), 1))
+    zero = ~d.any(axis=1)
+    d[zero] = [0.0, 0.0, 1.0]
+    norm = rng.random(n) < 0.5
+    d[norm] /= np.linalg.norm(d[norm], axis=1, keepdims=True)
+    return np.concatenate([o, d], axis=1)
+
+
 def random_case(seed, sizes=((64, 36), (96, 54), (128, 72)), counts=(17, 40, 96, 200, 512)):
+    if seed >= 40000:
+        return _fifth_wave(seed, sizes)
     if seed >= 20000:
         return _fourth_wave(seed, sizes)
     if seed >= 5000:
@@ -357,3 +457,61 @@ def test_hip_random_scenes_special_rays(hip, orc, seed, monkeypatch):
     for path in ("1", "4"):
         monkeypatch.setenv("RTC_KERNEL", path)
         assert_ray_parity_with_panics(hip, orc, world, rays, min(fuel, 3), label=label + " special rays, path " + path)
+
+
+def _lattice_seeds():
+    if "RTC_FUZZ_LATTICE_SEEDS" in os.environ:
+        first = int(os.environ.get("RTC_FUZZ_FIRST", "40000"))
+        return list(range(first, first + int(os.environ["RTC_FUZZ_LATTICE_SEEDS"])))
+    return list(range(40000, 40024))
+
+
+def _lattice_check(backend, orc, seed, label_suffix=""):
+    """One lattice scene (_fifth_wave): lattice rays and special-point rays through World::color_at (relative colour tolerance: every
+    second direction is not a unit vector), panicking rays refused one by one; then the scene through its camera with the digest, unless
+    the reference panics on that frame (then the device must refuse it too)."""
+    import cases
+    from parity import assert_ray_parity_with_panics, _raises
+    cam, world, fuel, label = random_case(seed, sizes=((48, 27),))
+    label += label_suffix
+    assert_ray_parity_with_panics(backend, orc, world, lattice_rays(1536, seed), fuel, label=label + " lattice rays", rel=True, max_panics=1536)
+    assert_ray_parity_with_panics(backend, orc, world, cases.special_rays(world, 768, seed=seed), fuel, label=label + " special rays", rel=True, max_panics=768)
+    try:
+        ref = oracle_reference(orc, world, cam, fuel)
+    except Exception as ex:  # noqa: BLE001
+        assert "NaN" in str(ex)
+        with pytest.raises(Exception, match="NaN"):
+            backend.render(backend.build_world(world), cam, fuel)
+        return
+    assert_parity(backend, orc, world, cam, fuel, label=label + " camera", ref=ref)
+
+
+@pytest.mark.parametrize("seed", list(range(40000, 40008)))
+def test_lattice_scenes_in_the_emulator(emu, orc, seed, monkeypatch):
+    for path in ("1", "4"):
+        monkeypatch.setenv("RTC_KERNEL", path)
+        _lattice_check(emu, orc, seed, " emulated path " + path)
+
+
+def test_world_without_lights_traces_no_secondary_rays(emu, orc):
+    """Found by the lattice scenes (the first generator with light-less worlds): World::shade_hit calls reflected_color and
+    refracted_color INSIDE its loop over the lights (src/world.rs:58-79), so a world without lights traces no secondary ray: every hit
+    is black, and a mirror facing two planes -- whose reflected NaN-free rays are harmless, but whose digest would count them -- has
+    the digest of its primary hits only."""
+    import cases
+    world = cases.SMALL_CASES["nested_glass"]()[1]
+    cam = cases.SMALL_CASES["nested_glass"]()[0]
+    dark = World([], world.elements)
+    nw = emu.build_world(dark)
+    rgb, hits = emu.render(nw, cam, 5)
+    assert not rgb.any() and (hits["prim"] >= 0).any()
+    assert np.array_equal(emu.render_digest(nw, cam, 5), emu.render_digest(nw, cam, 0))
+    assert_parity(emu, orc, dark, cam, 5, label="nested_glass without lights")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", _lattice_seeds())
+def test_hip_lattice_scenes(hip, orc, seed, monkeypatch):
+    for path in ("1", "4"):
+        monkeypatch.setenv("RTC_KERNEL", path)
+        _lattice_check(hip, orc, seed, " path " + path)
