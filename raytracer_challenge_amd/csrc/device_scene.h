@@ -40,7 +40,8 @@ struct DOp {  // 32 bytes
 struct DPlaneK {  // 72 bytes: what Plane::intersect reads (row 1 of transform_inv), the primitive's index, and the plane's world normal
   double row[4];
   int32_t prim;
-  int32_t pad[3];
+  int32_t gcond;   // innermost aggregation group above the plane (its Group::intersect gate, rtc_device.hpp groups_pass), -1: none
+  int32_t pad[2];
   double n[3];     // Shape::normal of the plane before the eye-side flip: the same for every point (scene_build.hpp plane_world_normal)
 };
 

@@ -899,6 +899,9 @@ __device__ TRAVERSE_INLINE void traverse(const DScene& S, const Ray& r, Trav& T,
         if (op.c >= 0) {
           // Plane (src/shape.rs:621-633): the same row-1 evaluation as visit_prim's plane case, operands from kernargs
           const DPlaneK P = S.kplanes[op.c];
+          // a plane under aggregation groups is reached through their box tests like any other child (src/shape.rs:251): a group
+          // that holds a plane has an unbounded or NaN-poisoned box, which a finite ray nearly always passes and a NaN ray never
+          if (FEAT >= 2 && P.gcond >= 0 && !kops_gate(S, P.gcond, r, T, C)) continue;
           C.analytic_tests++;
           C.kplanes++;
           DIAG_LOOP(8);

@@ -695,6 +695,7 @@ struct HostArrays {
         DPlaneK& k = d.kplanes[d.n_kplanes];
         std::memcpy(k.row, &xf_inv[(size_t)prims[(size_t)o.a].xform * 12 + 4], 4 * sizeof(double));
         k.prim = o.a;
+        k.gcond = prims[(size_t)o.a].gcond;
         plane_world_normal(&xf_inv[(size_t)prims[(size_t)o.a].xform * 12], k.n);
         o.c = d.n_kplanes++;
       }
