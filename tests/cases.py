@@ -282,6 +282,15 @@ def _special_points(world):
             for c in el.children:
                 walk(c, Mc)
             return
+        if el.tag == "obj":   # vertices of the file and midpoints of consecutive ones (edges of its quads / strips), at most 64
+            Mo = M @ np.array(el.transform.m, dtype=float)
+            try:
+                vs = [tuple(float(x) for x in ln.split()[1:4]) for ln in open(el.path) if ln.startswith("v ")][:64]
+            except OSError:
+                vs = []
+            mats.append(Mo)
+            add(Mo, vs + [tuple((np.array(a) + np.array(b)) / 2) for a, b in zip(vs, vs[1:])])
+            return
         if el.tag != "shape":
             return
         Ms = M @ np.array(el.args.transform.m, dtype=float)

@@ -209,7 +209,12 @@ def _fifth_wave(seed, sizes):
         if r < 0.6:
             return a
         t = Matrix.scaling(*[float(rng.choice([0.5, 1.0, 2.0]))] * 3)
-        return [Pattern.checkers, Pattern.stripes, Pattern.ring, Pattern.gradient][int(rng.integers(0, 4))](t, a, b)
+        base = [Pattern.checkers, Pattern.stripes, Pattern.ring, Pattern.gradient, Pattern.ring_gradient, Pattern.blend][int(rng.integers(0, 6))](t, a, b)
+        if r < 0.85:
+            return base
+        # Simplex / Fractal noise evaluated at lattice points (the skew's cell corners), jittering the point or the colour
+        noise = Noise.Simplex(float(rng.choice([0.25, 0.5, 1.0]))) if rng.random() < 0.5 else Noise.Fractal(float(rng.choice([0.25, 0.5])), int(rng.integers(1, 4)))
+        return Pattern.point_jitter(noise, base) if rng.random() < 0.5 else Pattern.color_jitter(noise, base)
 
     def material():
         r = rng.random()
@@ -245,10 +250,37 @@ def _fifth_wave(seed, sizes):
             return csg(depth + 1) if depth < 2 and rng.random() < 0.3 else prim(1)
         return Element.composite(transform(3), material() if rng.random() < 0.2 else None, kinds[int(rng.integers(0, 3))], [child(), child()])
 
+    def lattice_mesh():
+        """An OBJ grid mesh with integer x, z and half-integer heights (quads, fan-triangulated by the parser; with or without vertex
+        normals; sometimes two named groups): lattice rays pass exactly through its shared edges and through vertices six triangles
+        share -- equal t on neighbouring triangles, the lower sequence number wins."""
+        import tempfile
+        n, smooth, two = int(rng.integers(2, 6)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        path = os.path.join(tempfile.gettempdir(), "rtc_fuzz_lattice_%d_%d.obj" % (os.getpid(), seed))
+        hs = rng.choice([0.0, 0.0, 0.5, 1.0], (n + 1, n + 1))
+        with open(path, "w") as f:
+            for i in range(n + 1):
+                for j in range(n + 1):
+                    f.write("v %g %g %g\n" % (i - n // 2, hs[i, j], j - n // 2))
+            if smooth:
+                for i in range(n + 1):
+                    for j in range(n + 1):
+                        f.write("vn %g %g %g\n" % (float(rng.integers(-1, 2)), 1.0, float(rng.integers(-1, 2))))
+            for i in range(n):
+                if two and i == n // 2:
+                    f.write("g second\n")
+                for j in range(n):
+                    a, b, c, d = i * (n + 1) + j + 1, (i + 1) * (n + 1) + j + 1, (i + 1) * (n + 1) + j + 2, i * (n + 1) + j + 2
+                    f.write(("f %d//%d %d//%d %d//%d %d//%d\n" % (a, a, b, b, c, c, d, d)) if smooth else ("f %d %d %d %d\n" % (a, b, c, d)))
+        return Element.obj(path, transform(3), material())
+
     els = []
     for _ in range(int(rng.integers(3, 25))):
         r = rng.random()
-        if r < 0.6:
+        if r < 0.08:
+            m = lattice_mesh()
+            els.append(m if rng.random() < 0.5 else Element.composite(transform(2), None, GroupKind.Aggregation, [m, prim(2)]))
+        elif r < 0.6:
             els.append(prim())
         elif r < 0.8:
             els.append(Element.composite(transform(3), material() if rng.random() < 0.3 else None, GroupKind.Aggregation, [prim(2) for _ in range(int(rng.integers(1, 6)))]))
