@@ -26,12 +26,12 @@ typedef struct rtc_scene rtc_scene;
 
 enum {
   RTC_OK = 0,
-  RTC_ERR_INVALID = 1,     /* malformed description (index out of range, pattern too deep, ...)        */
+  RTC_ERR_INVALID = 1,     /* malformed description (index out of range, cyclic pattern nodes, ...)    */
   RTC_ERR_UNSUPPORTED = 2, /* valid in the reference, beyond a device limit: CSG groups nested deeper than 32; a
                               pattern with more than RTC_MAX_PATTERN_DEPTH colour frames on one path (below); a launch
                               whose CSG intersection slab would exceed RTC_CSG_MAX_BYTES (16 GiB: a subtree with more
                               than 32 possible intersections gets that many rows per thread); a material whose
-                              refractive_index is not in (1e-70, 1e70)                                  */
+                              refractive_index is not in (1e-70, 1e70); more than 64 lights; fuel above 16 */
   RTC_ERR_DEVICE = 3,      /* HIP failure / no device                                                   */
   RTC_ERR_NAN = 4          /* a NaN intersection t reached a sort the reference's comparator would run on: a list
                               of two or more entries of one World::intersect or CSG child list; the reference

@@ -270,7 +270,7 @@ typedef std::function<int()> AfterLaunch;
 int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* d_rgb, bool want_hits, rtc_stats* stats, bool count, bool sync, int force = 0,
         const AfterLaunch* after = nullptr) {
   if (fuel < 0) fuel = 0;  // fuel <= 0 spawns nothing (src/world.rs:90,110)
-  if (fuel > RTC_MAX_FUEL) return rtc_fail(RTC_ERR_INVALID, "fuel exceeds RTC_MAX_FUEL");
+  if (fuel > RTC_MAX_FUEL) return rtc_fail(RTC_ERR_UNSUPPORTED, "fuel exceeds RTC_MAX_FUEL (16): the reference recurses without a limit, the device keeps its pending rays per lane");
   // World::shade_hit calls reflected_color / refracted_color inside its loop over the lights (src/world.rs:58-79): a world without
   // lights traces no secondary ray at all (and shades every hit black)
   if (s->d.n_lights == 0) fuel = 0;

@@ -750,7 +750,7 @@ struct HostArrays {
 inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err, bvh::DeviceBuildFn device_build = nullptr, size_t device_build_min = 4096) {
   int rc = validate(D, err);
   if (rc != RTC_OK) return rc;
-  if (D.n_lights > 64) { *err = "more than 64 lights"; return RTC_ERR_INVALID; }
+  if (D.n_lights > 64) { *err = "more than 64 lights (the wavefront path keeps one shadow bit per light)"; return RTC_ERR_UNSUPPORTED; }
   const bool timing = std::getenv("RTC_TIMING") != nullptr;
   auto t_start = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {

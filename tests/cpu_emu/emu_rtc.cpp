@@ -28,7 +28,7 @@ static int efail(int c, const std::string& m) { g_err = m; return c; }
 static int run(rtc_scene* s, const DCamera& cam, DPixelMap pm, int fuel, double* rgb, rtc_hit* hits, rtc_stats* stats, unsigned long long* digest = nullptr) {
   pm.digest = digest;
   if (fuel < 0) fuel = 0;
-  if (fuel > RTC_MAX_FUEL) return efail(RTC_ERR_INVALID, "fuel exceeds RTC_MAX_FUEL");
+  if (fuel > RTC_MAX_FUEL) return efail(RTC_ERR_UNSUPPORTED, "fuel exceeds RTC_MAX_FUEL");
   if (s->d.n_lights == 0) fuel = 0;  // as rtc_scene.cpp run(): no lights, no secondary rays (src/world.rs:58-79)
   std::vector<double> t(hits ? pm.n : 0);
   std::vector<int> p(hits ? pm.n : 0), k(hits ? pm.n : 0);
