@@ -389,8 +389,10 @@ fn rtc_camera(camera: &Camera) -> RtcCamera {
 
 /// `Image::par_render`'s pixels on the MI355X: row-major `Vec<Color>` of `hsize * vsize`, as the reference collects them
 /// (src/image.rs:66-74).  `fuel` is the reference's compile-time `FUEL` (src/config.rs:2).  All visible devices are used
-/// (rows interleaved by device, gathered to the first); `Err(code == RTC_ERR_UNSUPPORTED)` = a scene beyond a device limit
-/// (CSG groups nested deeper than 8; an intersection slab beyond the memory budget): keep the CPU body for that scene.
+/// (8-row bands dealt round-robin over the devices, gathered to the first); `Err(code == RTC_ERR_UNSUPPORTED)` = a scene beyond a
+/// device limit (include/rtc.h: CSG groups nested deeper than 32, more than 8 colour frames on one pattern path, more than 64 lights,
+/// fuel above 16, a refractive index outside (1e-70, 1e70), an intersection slab beyond the memory budget): keep the CPU body for
+/// that scene.  `RTC_ERR_NAN` = the reference would have panicked in `Intersection::sort`: panic here too.
 pub fn render(camera: &Camera, world: &World, fuel: i32) -> Result<Vec<Color>, GpuError> {
     let flat = Flat::from_world(world);
     let desc = flat.desc();
