@@ -307,3 +307,19 @@ def test_emulated_kernel_special_point_rays(emu, orc, name):
     reference panics (a NaN t in a sorted list of two or more) must be refused one by one; all others match hit for hit."""
     _, world = cases.SMALL_CASES[name]()
     assert_ray_parity_with_panics(emu, orc, world, cases.special_rays(world, 3072), 5, label="special rays " + name)
+
+
+def test_sixty_four_lights_and_one_more(emu, orc, monkeypatch):
+    """64 lights is the device's limit (one shadow bit per light in the wavefront path's shade records); the reference re-traces every
+    secondary subtree once per light, so fuel 1 keeps the oracle at 64^2 traces per pixel.  65 lights are refused loudly."""
+    cam, world = cases.SMALL_CASES["all_primitives"]()
+    rng = np.random.default_rng(5)
+    lights = [PointLight(Color.new(*rng.uniform(0.01, 0.05, 3)), Vector.point(*rng.uniform(-10, 10, 3))) for _ in range(64)]
+    small = Camera.new(24, 14, cam.field_of_view, cam.transform_matrix)
+    for path in ("1", "4"):
+        monkeypatch.setenv("RTC_KERNEL", path)
+        assert_parity(emu, orc, World(lights, world.elements), small, 1, label="64 lights, path " + path)
+    with pytest.raises(rt.backend.RtwError, match="64 lights"):
+        emu.render(emu.build_world(World(lights + lights[:1], world.elements)), small, 1)
+    with pytest.raises(rt.backend.RtwError, match="RTC_MAX_FUEL"):
+        emu.render(emu.build_world(world), small, 17)
