@@ -171,6 +171,9 @@ struct DScene {
   int32_t light_grid_first;  // 0 or 1 + index in qgrids of light 0's light grid (= the b of the program's OP_BVH)
   int32_t all_plain;         // 1: every material's pattern is a Plain colour (Pattern::color_at never walks a tree: kernels without the pattern stack)
   int32_t no_glass_mirror;   // 1: no material both reflects and refracts (a hit never has two children: the one-kernel path stacks no pending ray)
+  int32_t backface_skip;     // 1: a shadow ray towards a light BEHIND the surface is answered without a traversal (rtc_device.hpp
+                             // light_is_behind; one-kernel path): matrices, triangle corners and lights are all below 1e30 in magnitude and no
+                             // matrix flattens space, so a finite shadow ray cannot produce a NaN t
   int32_t has_recs;          // 1: some op reads intersection records (pisect): analytic BVH, quirk scans, primitives outside the kernel arguments
   // Kernel-argument copy of a short traversal program (kernargs are read with scalar loads: the op fetch and the plane
   // records stop being per-lane vector loads on every ray's dependency chain).  Used when n_kops > 0: the whole program

@@ -1304,6 +1304,20 @@ __device__ __forceinline__ double blend_reflectance(const State& st, double n1, 
   return R;
 }
 
+// A light BEHIND the surface: Shape::lighting adds diffuse and specular only if `!shadowed && light . normal >= 0`
+// (src/shape.rs:448-459), so where light . normal < 0 the answer of World::is_shadowed cannot change the pixel, and the shadow ray
+// need not be traced -- PROVIDED tracing it could not have panicked either: the reference sorts its intersections whatever the answer
+// is worth, and a NaN t in a list of two or more panics.  A finite ray cannot make a NaN t while no intermediate of the intersection
+// formulas overflows (planes, triangles and the quadrics divide by quantities they have just compared with EPSILON; a cube's
+// 0 * inf is ignored by f64::max / min unless all three axes have one; infinite limits give infinite, not NaN, cap t's), which
+// DScene.backface_skip vouches for together with the bound on |v| here.  The decision uses v . n with a margin of 1e-6 |v| -- far
+// outside the rounding of the reference's own `(v / |v|) . n` (~1e-15), so every ray skipped here has a computed light . normal
+// below zero; NaN operands fail the comparisons (then the ray is traced).  v = light - over_point, n = the unit normal.
+__device__ __forceinline__ bool light_is_behind(const DScene& S, double vx, double vy, double vz, double nx, double ny, double nz) {
+  const double vn = vx * nx + vy * ny + vz * nz, vv = vx * vx + vy * vy + vz * vz;
+  return S.backface_skip && vn < 0.0 && vn * vn > 1e-12 * vv && vv < 1e60;
+}
+
 __device__ __forceinline__ void reset_closest(Trav& T, int mode) {
   T.mode = mode;
   T.tlo = 0.0; T.thi = DINF;
@@ -1514,11 +1528,16 @@ __global__ void __launch_bounds__(RTC_BLOCK, WAVES ? WAVES : ((FEAT >= 2 && RTC_
           DIAG_LOOP(5);
           const double* LG = S.lights + 6 * l;
           double vx = LG[3] - st.px, vy = LG[4] - st.py, vz = LG[5] - st.pz;
+          n_shadow++;
+          if (light_is_behind(S, vx, vy, vz, st.nx, st.ny, st.nz)) {  // ambient term only, in the expression of the general case
+            const double lr = (cr * LG[0]) * ambient, lg = (cg * LG[1]) * ambient, lb = (cb * LG[2]) * ambient;
+            sr += (lr + 0.0) + 0.0; sg += (lg + 0.0) + 0.0; sb += (lb + 0.0) + 0.0;
+            continue;
+          }
           double distance = sqrt(vx * vx + vy * vy + vz * vz);
           Ray sray;
           sray.ox = st.px; sray.oy = st.py; sray.oz = st.pz;
           sray.dx = vx / distance; sray.dy = vy / distance; sray.dz = vz / distance;
-          n_shadow++;
           Trav Sh;
           reset_closest(Sh, S.all_cast_shadow ? MODE_SHADOW_ANY : MODE_SHADOW_CLOSEST);
           if (S.all_cast_shadow) Sh.thi = distance;
@@ -1737,6 +1756,8 @@ __device__ __forceinline__ void wf_shadow_rec(const DScene& S, const DCamera& ca
   const double px = r[s], py = r[cap + s], pz = r[2 * cap + s];
   // World::shade_hit (src/world.rs:50-82): per light, shadow test + Phong (src/shape.rs:429-462).  First every shadow
   // ray (only the point is live across the traversals), then the Phong terms with the rest of the record.
+  // (light_is_behind() is not used here: on the scenes this path serves few lights are behind their surfaces -- most hits are on the
+  // floor -- and the mask's live range cost the traversal kernel 2.5 % at its register budget, whether or not a ray was skipped)
   unsigned long long shadow_mask = 0ull;  // <= 64 lights (checked at scene creation)
   for (int l = 0; l < S.n_lights; l++) {
     const double* LG = S.lights + 6 * l;

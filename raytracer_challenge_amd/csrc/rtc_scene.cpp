@@ -511,6 +511,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
     d.has_recs = hv.has_recs;
     d.all_plain = hv.all_plain;
     d.no_glass_mirror = hv.no_glass_mirror;
+    d.backface_skip = hv.backface_skip;
     d.light_grid_first = hv.light_grid_first;
     d.quirk_reach2 = hv.quirk_reach2;
     std::memcpy(d.abvh_frame, hv.abvh_frame, sizeof(d.abvh_frame));

@@ -652,6 +652,7 @@ struct HostArrays {
   std::vector<int32_t> mat_pattern;
   std::vector<DPat> pats;
   std::vector<double> lights;
+  mutable int backface_cached = -1;  // view(): the magnitude scan behind DScene.backface_skip, done once
   int32_t n_lights = 0, all_cast_shadow = 1, bvh_depth = 0, bvh_stack = 8, csg_max_hits = 0, built_on_device = 0;
   double quirk_reach2 = 0.0, abvh_frame[4] = {0, 0, 0, 0};  // see DScene
 
@@ -736,6 +737,25 @@ struct HostArrays {
     for (int32_t root : mat_pattern) if (root < 0 || (size_t)root >= pats.size() || pats[(size_t)root].tag != 1) d.all_plain = 0;
     d.no_glass_mirror = 1;
     for (size_t m = 0; m + 7 < mat.size(); m += 8) if (mat[m + 4] != 0.0 && mat[m + 5] != 0.0) d.no_glass_mirror = 0;
+    {
+      // light_is_behind() relies on a finite ray never producing a NaN t (the reference would panic on one in a list of two or more,
+      // whether or not the shadow test's answer matters): true while no intermediate of the intersection formulas can overflow
+      const char* env = std::getenv("RTC_BACKFACE_SKIP");
+      const bool on = !(env && env[0] == '0');
+      auto bounded = [](const std::vector<double>& v) { for (double x : v) if (!(std::fabs(x) < 1e30)) return false; return true; };
+      // ... nor underflow: a sphere divides by a = |object-space direction|^2 unchecked, so the world -> object matrices must not shrink
+      // a unit vector below ~1e-90: sigma_min >= |det| / |M|_F^2 with |det| >= 1e-30 and entries < 1e30
+      auto not_flat = [](const std::vector<double>& m) {
+        for (size_t i = 0; i + 11 < m.size(); i += 12) {
+          const double* r = &m[i];
+          const double det = r[0] * (r[5] * r[10] - r[6] * r[9]) - r[1] * (r[4] * r[10] - r[6] * r[8]) + r[2] * (r[4] * r[9] - r[5] * r[8]);
+          if (!(std::fabs(det) >= 1e-30)) return false;
+        }
+        return true;
+      };
+      if (backface_cached < 0) backface_cached = (bounded(xf_inv) && not_flat(xf_inv) && bounded(tri_geo) && bounded(lights)) ? 1 : 0;
+      d.backface_skip = on ? backface_cached : 0;
+    }
     d.has_recs = 0;
     for (size_t i = 0; i < ops.size(); i++) {
       const DOp& o = ops[i];

@@ -115,3 +115,36 @@ def test_light_grid_build_has_a_work_budget(emu, orc):
     st = dr.render_rows(2, 0, 1, cam.vsize, out, count=True, sync=True)
     assert st["rays_shadow"] > 0 and st["light_grid_cells"] == 0
     assert_parity(emu, orc, world, cam, 2, label="light inside a cloud of large boxes (no grids)")
+
+
+def test_lights_behind_the_surface_are_answered_without_a_shadow_traversal(emu, orc, monkeypatch):
+    """One-kernel path (rtc_device.hpp light_is_behind): where `light . normal < 0` Shape::lighting ignores the shadow test's answer
+    (src/shape.rs:448-459), and a finite shadow ray cannot make the NaN t the reference would panic on, so the traversal is skipped: the
+    same image bit for bit, the same ray counts (the ray is answered, not dropped), fewer tests.  Scenes with unbounded coordinates or
+    space-flattening matrices keep tracing every shadow ray."""
+    import torch
+    from raytracer_challenge_amd.scene import Element, Matrix, ShapeArgs, World
+    cam, world = scenes.chapter15_teapot("teapot_low.obj", 96, 54)
+    monkeypatch.setenv("RTC_KERNEL", "1")
+    st = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RTC_BACKFACE_SKIP", flag)
+        dr = DeviceRenderer(emu, emu.build_world(world), cam, 0, _cpu_standin=True)
+        out = torch.empty(cam.vsize * cam.hsize * 3, dtype=torch.float64)
+        st[flag] = dr.render_rows(5, 0, 1, cam.vsize, out, count=True, sync=True)
+        st[flag]["img"] = out.clone()
+    assert torch.equal(st["0"]["img"], st["1"]["img"])
+    for k in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract"):
+        assert st["0"][k] == st["1"][k], k
+    assert st["1"]["tri_tests"] < 0.9 * st["0"]["tri_tests"] and st["1"]["accel_nodes"] < st["0"]["accel_nodes"]   # (the teapot's far side)
+    monkeypatch.delenv("RTC_BACKFACE_SKIP")
+    assert_parity(emu, orc, world, cam, 5, label="teapot, lights behind surfaces skipped")
+    # a sphere scaled by 1e40 (its world -> object matrix shrinks unit vectors to 1e-40: a = |d|^2 could underflow elsewhere): no skipping
+    far = World(world.lights, list(world.elements) + [Element.sphere(ShapeArgs(transform=Matrix.translation(0.0, -1e41, 0.0) * Matrix.scaling(1e40, 1e40, 1e40)))])
+    a = DeviceRenderer(emu, emu.build_world(far), cam, 0, _cpu_standin=True)
+    out = torch.empty(cam.vsize * cam.hsize * 3, dtype=torch.float64)
+    monkeypatch.setenv("RTC_BACKFACE_SKIP", "0")
+    off = DeviceRenderer(emu, emu.build_world(far), cam, 0, _cpu_standin=True).render_rows(5, 0, 1, cam.vsize, out, count=True, sync=True)
+    monkeypatch.delenv("RTC_BACKFACE_SKIP")
+    on = a.render_rows(5, 0, 1, cam.vsize, out, count=True, sync=True)
+    assert on["tri_tests"] == off["tri_tests"] and on["analytic_tests"] == off["analytic_tests"]
