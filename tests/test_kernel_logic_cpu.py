@@ -323,3 +323,20 @@ def test_sixty_four_lights_and_one_more(emu, orc, monkeypatch):
         emu.render(emu.build_world(World(lights + lights[:1], world.elements)), small, 1)
     with pytest.raises(rt.backend.RtwError, match="RTC_MAX_FUEL"):
         emu.render(emu.build_world(world), small, 17)
+
+
+def test_random_pixel_lists_with_repeats(emu, monkeypatch):
+    """rtc_render / rtc_render_hit_digest on unordered pixel lists with repeated indices (list lengths around the wave size): every
+    entry equals that pixel of the full frame, on both emulated paths."""
+    cam, world = scenes.chapter11_title(64, 36)
+    nw = emu.build_world(world)
+    full, full_hits = emu.render(nw, cam, 5)
+    full_dig = emu.render_digest(nw, cam, 5)
+    rng = np.random.default_rng(3)
+    for path in ("1", "4"):
+        monkeypatch.setenv("RTC_KERNEL", path)
+        for n in (1, 7, 64, 65, 500, 3000):
+            idx = rng.integers(0, 64 * 36, n).astype(np.uint64)
+            rgb, hits = emu.render(nw, cam, 5, idx)
+            assert np.array_equal(rgb, full[idx]) and np.array_equal(hits, full_hits[idx]), (path, n)
+            assert np.array_equal(emu.render_digest(nw, cam, 5, idx), full_dig[idx]), (path, n)

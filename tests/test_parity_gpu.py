@@ -363,3 +363,19 @@ def test_hip_far_rays(hip, orc):
     for name in ("all_primitives", "cube_lattice", "synthetic_mesh_small", "synthetic_cones_grouped"):
         _, world = cases.SMALL_CASES[name]()
         assert_ray_parity(hip, orc, world, cases.far_rays(2048), 5, label="far " + name)
+
+
+def test_hip_random_pixel_lists_with_repeats(hip, monkeypatch):
+    """As tests/test_kernel_logic_cpu.py: unordered pixel lists with repeated indices against the full frame, both device paths."""
+    cam, world = scenes.chapter11_title(256, 144)
+    nw = hip.build_world(world)
+    full, full_hits = hip.render(nw, cam, 5)
+    full_dig = hip.render_digest(nw, cam, 5)
+    rng = np.random.default_rng(3)
+    for path in ("1", "4"):
+        monkeypatch.setenv("RTC_KERNEL", path)
+        for n in (1, 63, 64, 65, 4097, 100000):
+            idx = rng.integers(0, 256 * 144, n).astype(np.uint64)
+            rgb, hits = hip.render(nw, cam, 5, idx)
+            assert np.array_equal(rgb, full[idx]) and np.array_equal(hits, full_hits[idx]), (path, n)
+            assert np.array_equal(hip.render_digest(nw, cam, 5, idx), full_dig[idx]), (path, n)
