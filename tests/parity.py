@@ -26,7 +26,7 @@ def oracle_reference(orc, world, camera, fuel=5, pixel_indices=None, threads=0):
     return orc.render_with_digest(orc.build_world(world), camera, fuel, pixel_indices, threads=threads)
 
 
-def assert_parity(test_backend, orc, world, camera, fuel=5, pixel_indices=None, label="", digest=True, ref=None):
+def assert_parity(test_backend, orc, world, camera, fuel=5, pixel_indices=None, label="", digest=True, ref=None, rel=False):
     """Hit records must be bit-exact: the primary hit of every pixel (t as u64 bits, primitive sequence number, push index) and,
     through the hit-tree digest (include/rtc.h rtc_render_hit_digest), every closest hit of every pixel's ray tree — reflected and
     refracted rays at every depth; colours within RGB_TOL."""
@@ -47,7 +47,7 @@ def assert_parity(test_backend, orc, world, camera, fuel=5, pixel_indices=None, 
         bad_d = dig != ref_dig
         assert not bad_d.any(), "%s: the hit-tree digests of %d/%d pixels differ (a closest hit somewhere below the primary one), first at %s" % (
             label, int(bad_d.sum()), bad_d.size, np.flatnonzero(bad_d)[:5])
-    err = rgb_error(rgb, ref_rgb, label)
+    err = rgb_error(rgb, ref_rgb, label, rel)
     assert err <= RGB_TOL, "%s: max |dRGB| = %.3e > %.0e" % (label, err, RGB_TOL)
     return err
 

@@ -309,7 +309,43 @@ def lattice_rays(n, seed):
     return np.concatenate([o, d], axis=1)
 
 
+def _sixth_wave(seed, sizes):
+    """Seeds >= 60000: ORDINARY geometry, EXTREME parameters -- materials with shininess 0 / negative / 1e6 / fractional, specular and
+    ambient above 1, negative diffuse, reflective and transparency above 1, refractive indices below 1, lights with negative, huge or
+    zero intensity, a light at the camera; cameras of 1 x 1, 1 x N, N x 1 and other sizes below and off the 8 x 8 tile, fields of view
+    from 0.01 to just under pi; fuels up to the device's 16.  `sizes` is ignored."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([6, 17, 40]))
+    cam0, world = scenes.synthetic_analytic(n_primitives=n, seed=int(rng.integers(1, 1 << 30)), cones=bool(rng.integers(0, 2)), grouped=bool(rng.integers(0, 2)), hsize=32, vsize=18)
+
+    def extreme(m):
+        pick = lambda xs: float(xs[int(rng.integers(0, len(xs)))])
+        return dataclasses.replace(
+            m, ambient=pick([0.0, 0.1, 1.5, -0.2]), diffuse=pick([0.0, 0.9, 2.0, -0.5]), specular=pick([0.0, 0.9, 3.0, -1.0]),
+            shininess=pick([0.0, 0.5, 1.0, 200.0, 1e6, 2e6, -1.0, -200.0, 7.3]), reflective=pick([0.0, 0.0, 0.5, 1.0, 1.7]),
+            transparency=pick([0.0, 0.0, 0.5, 1.0, 1.3]), refractive_index=pick([1.0, 1.5, 0.5, 0.9, 3.0]))
+
+    for e in _shapes(world.elements):
+        if rng.random() < 0.7:
+            object.__setattr__(e, "args", dataclasses.replace(e.args, material=extreme(e.args.material)))
+    lights = []
+    for _ in range(int(rng.choice([1, 1, 2, 3]))):
+        inten = [float(x) for x in rng.choice([0.0, 0.3, 1.0, 5.0, -0.5, 1e6], 3)]
+        lights.append(PointLight(Color.new(*inten), Vector.point(float(rng.uniform(-15, 15)), float(rng.uniform(1, 20)), float(rng.uniform(-15, 10)))))
+    frm = Vector.point(float(rng.uniform(-6, 6)), float(rng.uniform(1, 8)), float(rng.uniform(-14, -6)))
+    if rng.random() < 0.3:
+        lights.append(PointLight(Color.new(0.5, 0.5, 0.5), frm))   # a light exactly at the camera
+    world = World(lights, world.elements)
+    h, v = [(1, 1), (1, 9), (9, 1), (7, 3), (13, 5), (8, 8), (17, 9), (33, 20), (64, 2)][int(rng.integers(0, 9))]
+    fov = float(rng.choice([0.01, 0.5, 1.2, 3.0, 3.14, 3.1415]))
+    cam = Camera.new(h, v, fov, Camera.transform(frm, Vector.point(0, 1, 2), Vector.vector(0, 1, 0)))
+    fuel = int(rng.choice([0, 1, 5, 9, 16])) if len(lights) == 1 else int(rng.choice([0, 1, 3, 5]))
+    return cam, world, fuel, "fuzz seed %d (sixth wave: extreme parameters, n=%d lights=%d fuel=%d %dx%d fov %g)" % (seed, n, len(lights), fuel, h, v, fov)
+
+
 def random_case(seed, sizes=((64, 36), (96, 54), (128, 72)), counts=(17, 40, 96, 200, 512)):
+    if seed >= 60000:
+        return _sixth_wave(seed, sizes)
     if seed >= 40000:
         return _fifth_wave(seed, sizes)
     if seed >= 20000:
@@ -547,3 +583,35 @@ def test_hip_lattice_scenes(hip, orc, seed, monkeypatch):
     for path in ("1", "4"):
         monkeypatch.setenv("RTC_KERNEL", path)
         _lattice_check(hip, orc, seed, " path " + path)
+
+
+def _extreme_seeds():
+    if "RTC_FUZZ_EXTREME_SEEDS" in os.environ:
+        first = int(os.environ.get("RTC_FUZZ_FIRST", "60000"))
+        return list(range(first, first + int(os.environ["RTC_FUZZ_EXTREME_SEEDS"])))
+    return list(range(60000, 60016))
+
+
+def _extreme_check(backend, orc, seed, monkeypatch, tag):
+    import cases
+    from parity import assert_ray_parity_with_panics
+    cam, world, fuel, label = random_case(seed)
+    ref = oracle_reference(orc, world, cam, fuel)
+    rays = cases.special_rays(world, 512, seed=seed)
+    for path in ("1", "4"):
+        monkeypatch.setenv("RTC_KERNEL", path)
+        assert_parity(backend, orc, world, cam, fuel, label="%s %s path %s" % (label, tag, path), ref=ref, rel=True)
+        assert_ray_parity_with_panics(backend, orc, world, rays, min(fuel, 3), label="%s %s special rays path %s" % (label, tag, path), rel=True)
+
+
+@pytest.mark.parametrize("seed", list(range(60000, 60006)))
+def test_extreme_parameters_in_the_emulator(emu, orc, seed, monkeypatch):
+    """_sixth_wave: ordinary geometry under extreme materials, lights and cameras (colours compared relative to max(1, |reference|):
+    an intensity of 1e6 and a specular coefficient of 3 leave the unit range)."""
+    _extreme_check(emu, orc, seed, monkeypatch, "emulated")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", _extreme_seeds())
+def test_hip_extreme_parameters(hip, orc, seed, monkeypatch):
+    _extreme_check(hip, orc, seed, monkeypatch, "")
