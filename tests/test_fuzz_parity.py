@@ -2,7 +2,14 @@
 cluster, some on the floor plane), CSG groups under transformed aggregation groups, smooth-triangle meshes under groups, fuels and
 resolutions, both device paths against the oracle — the primary hit of every pixel and the digest of every closest hit of its ray
 tree bit-exact, colours within 1e-5.  Light grids, the container passes' point test and the group gates all decide per ray which exact tests run; a scene generator
-that nobody tuned the kernels on is the cheapest way to catch a wrong decision.  RTC_FUZZ_SEEDS=<n> runs more seeds on the GPU."""
+that nobody tuned the kernels on is the cheapest way to catch a wrong decision.  RTC_FUZZ_SEEDS=<n> runs more seeds on the GPU.
+
+Six scene generators by seed range (random_case): < 3000 synthetic clouds with lights inside, CSG and meshes; >= 3000 + glass meshes,
+shadowless primitives, procedural patterns, cameras inside the cloud; >= 5000 scenes from scratch (deep groups, five decades of scale);
+>= 20000 CSG trees; >= 40000 LATTICE scenes (exact transforms, integer geometry: ties and thresholds everywhere); >= 60000 ordinary
+geometry under extreme materials / lights / cameras.  Three ray generators beside the cameras: cases.edge_rays, cases.special_rays (aimed
+at the primitives' apexes, rims, corners, poles, vertices), lattice_rays.  Rays and frames on which the reference PANICS are part of the
+contract: the device must refuse them (tests/parity.py assert_ray_parity_with_panics).  DESIGN.md section 2 lists what each one found."""
 import dataclasses
 import math
 import os
