@@ -647,7 +647,9 @@ def main():
                                      "frames: whole frames round-robin over the ranks, F in flight per GPU, a round of N frames gathered to rank 0 over RCCL (same bytes per frame as bands)"
                                      if m["partition"] == "frames" else "bands: every frame in 8-row bands dealt round-robin by rank, RCCL gather to rank 0"),
                        "frames_in_flight": F, "process_group": {"world_size": world_size, "backend": backend_name},
-                       "unique_rays_per_frame": m["rays_total"], "rays_per_pixel": m["rays_total"] / (H * V)},
+                       "unique_rays_per_frame": m["rays_total"], "rays_per_pixel": m["rays_total"] / (H * V),
+                       "ray_count": "rays of the reference's de-duplicated ray tree (device counters = the oracle's); on the one-kernel path a shadow ray "
+                                    "towards a light behind the surface is counted and answered without a traversal (DESIGN.md 4.13)"},
             "roofline": m["roofline"],
             "accelerator": dict(m["info"], ingest=m["ingest"]),
         }
