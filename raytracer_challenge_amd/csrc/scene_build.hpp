@@ -742,7 +742,13 @@ struct HostArrays {
       // whether or not the shadow test's answer matters): true while no intermediate of the intersection formulas can overflow
       const char* env = std::getenv("RTC_BACKFACE_SKIP");
       const bool on = !(env && env[0] == '0');
-      auto bounded = [](const std::vector<double>& v) { for (double x : v) if (!(std::fabs(x) < 1e30)) return false; return true; };
+      auto bounded = [](const std::vector<double>& v) {  // (9 doubles per triangle: threaded for the meshes that matter)
+        std::atomic<bool> ok{true};
+        parallel_for(v.size(), 1u << 20, [&](size_t b, size_t e) {
+          for (size_t i = b; i < e; i++) if (!(std::fabs(v[i]) < 1e30)) { ok = false; return; }
+        });
+        return ok.load();
+      };
       // ... nor underflow: a sphere divides by a = |object-space direction|^2 unchecked, so the world -> object matrices must not shrink
       // a unit vector below ~1e-90: sigma_min >= |det| / |M|_F^2 with |det| >= 1e-30 and entries < 1e30
       auto not_flat = [](const std::vector<double>& m) {
