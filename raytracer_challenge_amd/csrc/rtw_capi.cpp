@@ -40,13 +40,21 @@ static Mat to_mat(const rtw_material* m) {
 
 static int ensure_scene(rtw_world* w) {
   if (w->scene) return 0;
+  const bool timing = std::getenv("RTC_TIMING") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
-  Flat f;
-  Flattener fl(f);
-  if (!fl.run(w->w)) return fail("flatten: " + f.error);
-  rtc_scene_desc d = f.desc();
-  if (std::getenv("RTC_TIMING")) std::fprintf(stderr, "[rtc-timing] %-28s %.3f s\n", "flatten (host mirror -> desc)", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-  int rc = rtc_scene_create(&d, w->device, &w->scene);
+  auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
+  int rc;
+  {
+    Flat f;
+    Flattener fl(f);
+    if (!fl.run(w->w)) return fail("flatten: " + f.error);
+    rtc_scene_desc d = f.desc();
+    if (timing) std::fprintf(stderr, "[rtc-timing] %-28s %.3f s\n", "flatten (host mirror -> desc)", since(t0));
+    const auto t1 = std::chrono::steady_clock::now();
+    rc = rtc_scene_create(&d, w->device, &w->scene);
+    if (timing) std::fprintf(stderr, "[rtc-timing] %-28s %.3f s\n", "rtc_scene_create (all of it)", since(t1));
+  }
+  if (timing) std::fprintf(stderr, "[rtc-timing] %-28s %.3f s\n", "flatten + create + frees", since(t0));
   if (rc != RTC_OK) return fail(std::string("rtc_scene_create: ") + rtc_last_error());
   return 0;
 }
