@@ -175,6 +175,8 @@ struct DScene {
                              // light_is_behind; one-kernel path): matrices, triangle corners and lights are all below 1e30 in magnitude and no
                              // matrix flattens space, so a finite shadow ray cannot produce a NaN t
   int32_t has_recs;          // 1: some op reads intersection records (pisect): analytic BVH, quirk scans, primitives outside the kernel arguments
+  int32_t n_recs;            // entries of pisect: 0, or 1 + the last primitive an op can name (scene_build.hpp build_arrays) -- NOT n_prims: the
+                             // triangles of a mesh at the end of the world have no record
   // Kernel-argument copy of a short traversal program (kernargs are read with scalar loads: the op fetch and the plane
   // records stop being per-lane vector loads on every ray's dependency chain).  Used when n_kops > 0: the whole program
   // has <= RTC_KOPS ops, no OP_GROUP / OP_CSG, no per-primitive gates (so every lane runs the same op sequence); an

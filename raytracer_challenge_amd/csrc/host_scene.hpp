@@ -8,6 +8,8 @@
 // plain arrays of include/rtc.h.  Nothing here runs per pixel.  Build with -ffp-contract=off: these values
 // decide hits.
 #pragma once
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -16,6 +18,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rtc.h"
@@ -453,6 +456,22 @@ struct Flat {
   }
 };
 
+// [0, n) cut into one range per thread (at most 8, RTC_BUILD_THREADS overrides), for the flatten's fills
+template <class F>
+inline void par_ranges(size_t n, F fn) {
+  unsigned t = std::thread::hardware_concurrency();
+  if (const char* e = std::getenv("RTC_BUILD_THREADS")) t = (unsigned)std::max(1, std::atoi(e));
+  t = std::min<unsigned>(std::max(1u, t), 8u);
+  if (t < 2 || n < 65536) { fn((size_t)0, n); return; }
+  std::vector<std::thread> th;
+  const size_t per = (n + t - 1) / t;
+  for (unsigned k = 0; k < t; k++) {
+    const size_t b = std::min(n, per * k), e = std::min(n, per * (k + 1));
+    if (e > b) th.emplace_back([=] { fn(b, e); });
+  }
+  for (auto& x : th) x.join();
+}
+
 class Flattener {
  public:
   explicit Flattener(Flat& f) : f_(f) {}
@@ -570,9 +589,62 @@ class Flattener {
     std::memcpy(n.bbox_max, e.box.hi, sizeof(n.bbox_max));
     size_t self = f_.nodes.size();
     f_.nodes.push_back(n);
-    for (auto& k : e.kids)
-      if (!walk(*k)) return false;
+    if (e.kids.size() >= 32768 && !std::getenv("RTC_FLATTEN_SERIAL") && uniform_triangles(e)) {  // (the variable: tests compare the two)
+      if (!fill_uniform_triangles(e)) return false;
+    } else {
+      for (auto& k : e.kids)
+        if (!walk(*k)) return false;
+    }
     f_.nodes[self].skip = (int32_t)f_.nodes.size();
+    return true;
+  }
+  // A large group whose children are all triangles with one material and one set of matrices (what ObjParser makes of an OBJ group,
+  // src/obj.rs:186-258): the records of its children are the ones walk() would emit, written by several threads.
+  static bool same_prim_frame(const Elem& a, const Elem& b) {
+    const double sa[7] = {a.material.ambient, a.material.diffuse, a.material.specular, a.material.shininess, a.material.reflective, a.material.transparency, a.material.refractive_index};
+    const double sb[7] = {b.material.ambient, b.material.diffuse, b.material.specular, b.material.shininess, b.material.reflective, b.material.transparency, b.material.refractive_index};
+    return a.material.pattern.get() == b.material.pattern.get() && std::memcmp(sa, sb, sizeof(sa)) == 0 && std::memcmp(a.inv.a, b.inv.a, sizeof(a.inv.a)) == 0 &&
+           std::memcmp(a.mat_inv.a, b.mat_inv.a, sizeof(a.mat_inv.a)) == 0 && std::memcmp(a.inv_tsp.a, b.inv_tsp.a, sizeof(a.inv_tsp.a)) == 0;
+  }
+  static bool uniform_triangles(const Elem& g) {
+    const Elem& k0 = *g.kids[0];
+    std::atomic<bool> ok{true};
+    par_ranges(g.kids.size(), [&](size_t b, size_t e) {
+      for (size_t i = b; i < e; i++) {
+        const Elem& k = *g.kids[i];
+        if (k.group_kind != RTC_NODE_PRIM || k.geo.kind < RTC_TRIANGLE || !same_prim_frame(k, k0)) { ok = false; return; }
+      }
+    });
+    return ok.load();
+  }
+  bool fill_uniform_triangles(const Elem& g) {
+    const Elem& k0 = *g.kids[0];
+    const int32_t mid = material(k0.material), xid = xform(k0);
+    if (xid < 0) return false;
+    const size_t n = g.kids.size(), prim0 = f_.prims.size(), node0 = f_.nodes.size(), tri0 = f_.tri_geo.size() / 9;
+    f_.prims.resize(prim0 + n);
+    f_.nodes.resize(node0 + n);
+    f_.tri_geo.resize(9 * (tri0 + n));
+    f_.tri_nrm.resize(9 * (tri0 + n));
+    par_ranges(n, [&](size_t b, size_t e) {
+      for (size_t i = b; i < e; i++) {
+        const Elem& k = *g.kids[i];
+        rtc_prim p{};
+        p.geometry = k.geo.kind;
+        p.flags = (k.casts_shadow ? RTC_FLAG_CASTS_SHADOW : 0u) | (k.geo.closed ? RTC_FLAG_CLOSED : 0u);
+        p.material = mid;
+        p.xform = xid;
+        p.data = (int32_t)(tri0 + i);
+        f_.prims[prim0 + i] = p;
+        rtc_node nd{};
+        nd.kind = RTC_NODE_PRIM;
+        nd.ref = (int32_t)(prim0 + i);
+        nd.skip = (int32_t)(node0 + i + 1);
+        f_.nodes[node0 + i] = nd;
+        std::memcpy(&f_.tri_geo[9 * (tri0 + i)], k.geo.p1e1e2, 9 * sizeof(double));
+        std::memcpy(&f_.tri_nrm[9 * (tri0 + i)], k.geo.normals, 9 * sizeof(double));
+      }
+    });
     return true;
   }
 };

@@ -407,7 +407,7 @@ __device__ __forceinline__ DPrimI lds_record(const LdsScene& L, int prim) {
 // bytes of the tables (host + device agree on the layout: nodes, records, triangles, triangle -> primitive, 16-byte aligned pieces)
 static inline unsigned long long rtc_lds_table_bytes(const DScene& S) {
   unsigned long long b = 7ull * 16 * (unsigned)S.n_bvh;
-  if (S.has_recs) b += 8ull * 16 * (unsigned)S.n_prims;
+  if (S.has_recs) b += 8ull * 16 * (unsigned)S.n_recs;
   if (S.has_mesh) b += (72ull * (unsigned)S.n_mtri + 4ull * (unsigned)S.n_mtri + 15ull) & ~15ull;
   return b;
 }
@@ -423,9 +423,9 @@ __device__ __forceinline__ char* lds_fill(const DScene& S, char* base, LdsScene&
   if (S.has_recs) {
     float4* lr = (float4*)p;
     const float4* gr = (const float4*)S.pisect;
-    for (int k = (int)threadIdx.x; k < 8 * S.n_prims; k += (int)blockDim.x) { const int n = k >> 3, r = k & 7; lr[r * S.n_prims + n] = gr[k]; }
-    L.recs = lr; L.n_recs = S.n_prims;
-    p = (char*)(lr + 8 * (size_t)S.n_prims);
+    for (int k = (int)threadIdx.x; k < 8 * S.n_recs; k += (int)blockDim.x) { const int n = k >> 3, r = k & 7; lr[r * S.n_recs + n] = gr[k]; }
+    L.recs = lr; L.n_recs = S.n_recs;
+    p = (char*)(lr + 8 * (size_t)S.n_recs);
   }
   if (S.has_mesh) {
     double* lt = (double*)p;

@@ -500,6 +500,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, int device, rtc_scene** out) {
 #undef UP
   d.n_ops = (int32_t)H.ops.size();
   d.n_prims = (int32_t)H.prims.size();
+  d.n_recs = (int32_t)H.pisect.size();
   d.n_lights = H.n_lights;
   d.all_cast_shadow = H.all_cast_shadow;
   {

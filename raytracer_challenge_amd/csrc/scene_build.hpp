@@ -711,7 +711,7 @@ struct HostArrays {
     d.item_prim = items.data(); d.quirk_prim = items.data(); d.qgrids = qgrids.data(); d.qcell = qcell.data(); d.bvh_frame = bvh_frame.data(); d.csg = csg.data(); d.qitem = items.data(); d.prims = prims.data(); d.pisect = pisect.data(); d.xf_inv = xf_inv.data(); d.xf_matinv = xf_matinv.data(); d.limits = limits.data();
     d.tri_geo = tri_geo.data(); d.tri_nrm = tri_nrm.data(); d.mat = mat.data(); d.mat_pattern = mat_pattern.data(); d.pats = pats.data();
     d.lights = lights.data();
-    d.n_ops = (int32_t)ops.size(); d.n_prims = (int32_t)prims.size(); d.n_lights = n_lights; d.all_cast_shadow = all_cast_shadow;
+    d.n_ops = (int32_t)ops.size(); d.n_prims = (int32_t)prims.size(); d.n_recs = (int32_t)pisect.size(); d.n_lights = n_lights; d.all_cast_shadow = all_cast_shadow;
     d.n_bvh = (int32_t)bvh.size(); d.n_items = (int32_t)items.size(); d.n_mtri = (int32_t)mtri_prim.size(); d.n_quirk = (int32_t)items.size();
     d.n_qitem = (int32_t)items.size(); d.n_qcell = (int32_t)qcell.size(); d.n_groups = (int32_t)(group_box.size() / 6); d.n_qgrids = (int32_t)qgrids.size();
     d.bvh_stack = bvh_stack;
@@ -820,18 +820,6 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
     std::memcpy(&H->xf_matinv[(size_t)i * 16], D.xforms[i].material_inv, 16 * sizeof(double));
   }
   H->limits.assign(D.limits, D.limits + (size_t)D.n_limits * 2);
-  H->pisect.resize(D.n_prims);
-  parallel_for(D.n_prims, 65536, [&](size_t b, size_t e) {
-    for (size_t i = b; i < e; i++) {
-      const DPrim& P = H->prims[i];
-      DPrimI& q = H->pisect[i];
-      q.geom = P.geom; q.flags = P.flags; q.data = P.data; q.gcond = P.gcond;
-      const bool lim = P.geom == RTC_CYLINDER || P.geom == RTC_CONE;
-      q.mn = lim ? D.limits[2 * (size_t)P.data] : 0.0;
-      q.mx = lim ? D.limits[2 * (size_t)P.data + 1] : 0.0;
-      std::memcpy(q.m, &H->xf_inv[(size_t)P.xform * 12], 12 * sizeof(double));
-    }
-  });
   H->tri_geo.assign(D.tri_p1e1e2, D.tri_p1e1e2 + (size_t)D.n_tris * 9);
   H->tri_nrm.assign(D.tri_normals, D.tri_normals + (size_t)D.n_tris * 9);
   H->mat.assign((size_t)D.n_materials * 8, 0.0);
@@ -887,9 +875,36 @@ inline int build_arrays(const rtc_scene_desc& D, HostArrays* H, std::string* err
   H->csg_max_hits = pb.csg_max_hits;
   H->built_on_device = pb.built_on_device;
   H->bvh_stack = std::max(8, pb.max_stack + 1);
+  lap("moves");
   {  // planes whose record travels in the kernel arguments: the primitive names its slot (its world normal is read there, DPrim.pad)
     const DScene dv = H->view();
+    lap("view()");
     for (int i = 0; i < dv.n_kplanes; i++) H->prims[(size_t)dv.kplanes[i].prim].pad[0] = i + 1;
+    // the 128-byte intersection records, one per primitive -- only if some op of the program reads them (DScene.has_recs): a mesh
+    // and a few planes in the kernel arguments do not, and 10^6 triangles would carry 128 MB of them to the device for nothing
+    if (dv.has_recs) {
+      // ... and only up to the last primitive an op can name: the program's own OP_PRIMs (CSG sub-programs included) and the analytic
+      // BVH's primitives.  Mesh triangles are reached through their BVH's packed triangle array, never through a record; an OBJ
+      // group at the end of the world -- where the bins put it -- leaves the array a few entries long.
+      int64_t last = -1;
+      for (const DOp& o : H->ops) if (o.op == OP_PRIM) last = std::max<int64_t>(last, o.a);
+      for (int32_t pi : H->bvh_prims) last = std::max<int64_t>(last, pi);
+      const size_t n_rec = (size_t)(last + 1);
+      H->pisect.resize(n_rec);
+      parallel_for(n_rec, 65536, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; i++) {
+          const DPrim& P = H->prims[i];
+          DPrimI& q = H->pisect[i];
+          q.geom = P.geom; q.flags = P.flags; q.data = P.data; q.gcond = P.gcond;
+          const bool lim = P.geom == RTC_CYLINDER || P.geom == RTC_CONE;
+          q.mn = lim ? D.limits[2 * (size_t)P.data] : 0.0;
+          q.mx = lim ? D.limits[2 * (size_t)P.data + 1] : 0.0;
+          std::memcpy(q.m, &H->xf_inv[(size_t)P.xform * 12], 12 * sizeof(double));
+        }
+      });
+    }
+    if (timing) std::fprintf(stderr, "[rtc-timing]   %zu intersection records for %u primitives\n", H->pisect.size(), D.n_prims);
+    lap("intersection records");
   }
   return RTC_OK;
 }
